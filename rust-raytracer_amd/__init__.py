@@ -1,0 +1,309 @@
+"""Host-side Python mirror of the reference's Environment / Camera interface over librrt.so.
+
+The product is the C-ABI library (include/rrt.h); this module is a thin ctypes binding so tests and
+bench.py read like the reference's own call sites:
+
+    scene, camera = Scene.load("assets/scenes/quadratics.txt", root)   # SceneFile::from_path
+    scene.pre_render(seed=1)                                            # Environment::pre_render
+    rgb, depth, ids = scene.render(camera)                              # Camera::render
+
+There is no CPU fallback: if librrt.so is missing the import fails, and every compute call fails
+with ERR_DEVICE when no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import *  # noqa: F401,F403
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librrt.so")
+REPO_ROOT = os.path.dirname(_HERE)
+
+
+class RrtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("rrt error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "librrt.so is not built (%s): run `make -C rust-raytracer_amd/csrc` or __graft_entry__.build(); "
+            "there is no CPU fallback" % LIB_PATH
+        )
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_f32p = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_sig("rrt_last_error", C.c_char_p)
+_sig("rrt_version", C.c_char_p)
+_sig("rrt_params_default", None, C.POINTER(Params))
+_sig("rrt_scene_create", C.c_void_p, C.c_int, C.POINTER(Params))
+_sig("rrt_scene_destroy", None, C.c_void_p)
+_sig("rrt_scene_set_mode", C.c_int, C.c_void_p, C.c_int)
+_sig("rrt_scene_get_mode", C.c_int, C.c_void_p)
+_sig("rrt_scene_set_params", C.c_int, C.c_void_p, C.POINTER(Params))
+_sig("rrt_add_texture", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p)
+_sig("rrt_add_texture_ppm", C.c_int, C.c_void_p, C.c_char_p)
+_sig("rrt_add_material", C.c_int, C.c_void_p, C.POINTER(MaterialDesc))
+_sig("rrt_object_define", C.c_int, C.c_void_p, C.POINTER(ObjectDesc))
+_sig("rrt_object_define_obj", C.c_int, C.c_void_p, C.c_char_p, C.c_int, C.c_int)
+_sig("rrt_object_transform", C.c_int, C.c_void_p, C.c_int, _f32p)
+_sig("rrt_add_object", C.c_int, C.c_void_p, C.c_int)
+_sig("rrt_add_light", C.c_int, C.c_void_p, C.POINTER(LightDesc))
+_sig("rrt_object_count", C.c_int, C.c_void_p)
+_sig("rrt_light_count", C.c_int, C.c_void_p)
+_sig("rrt_scene_builder", C.c_void_p, C.c_void_p)
+_sig("rrt_camera_init", C.c_int, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_float, _f32p, _f32p, _f32p)
+_sig("rrt_camera_ray", C.c_int, C.POINTER(Camera), C.c_uint32, C.c_uint32, _f32p, _f32p)
+_sig("rrt_parse_scene_file", C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(Camera), C.c_int, _u32p)
+_sig("rrt_parse_scene_text", C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(Camera), C.c_int, _u32p)
+_sig("rrt_scene_load", C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(Params), C.c_int, C.POINTER(Camera))
+_sig("rrt_pre_render", C.c_int, C.c_void_p, C.c_uint64)
+_sig("rrt_render", C.c_int, C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, _f32p, _f32p, _u32p)
+_sig("rrt_render_device", C.c_int, C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("rrt_raytrace", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _f32p, _f32p, _u32p)
+_sig("rrt_trace", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _u32p, _u32p, _f32p, _f32p, _f32p, _f32p)
+_sig("rrt_shadowtrace", C.c_int, C.c_void_p, _f32p, _f32p, _f32p, C.c_size_t, _u8p)
+_sig("rrt_photon_begin", C.c_int, C.c_void_p, C.c_uint64)
+_sig("rrt_photon_shoot", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64)
+_sig("rrt_photon_build", C.c_int, C.c_void_p)
+_sig("rrt_get_stats", C.c_int, C.c_void_p, C.POINTER(Stats))
+_sig("rrt_quantise", None, _f32p, C.c_size_t, _u8p)
+_sig("rrt_write_rgb_ppm", C.c_int, C.c_char_p, _f32p, C.c_uint32, C.c_uint32)
+_sig("rrt_write_depth_pgm", C.c_int, C.c_char_p, _f32p, C.c_uint32, C.c_uint32)
+
+
+def last_error():
+    return lib.rrt_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc < 0:
+        raise RrtError(rc, last_error())
+    return rc
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def default_params(**overrides):
+    p = Params()
+    lib.rrt_params_default(C.byref(p))
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def make_camera(width, height, fov_radians, position, lookat, up=None, api=None):
+    """FullCamera::new (full_camera.rs:23-58). `up` defaults as scene_file.rs:577-582."""
+    if up is None:
+        up = (0.0, lookat[2], -lookat[1])
+    cam = Camera()
+    p, l, u = (_f32(position), _f32(lookat), _f32(up))
+    fn = lib.rrt_camera_init if api is None else api
+    check(fn(C.byref(cam), width, height, C.c_float(fov_radians), _fp(p), _fp(l), _fp(u)))
+    return cam
+
+
+def camera_ray(cam, x, y):
+    o = np.zeros(3, np.float32)
+    d = np.zeros(3, np.float32)
+    check(lib.rrt_camera_ray(C.byref(cam), x, y, _fp(o), _fp(d)))
+    return o, d
+
+
+def parse_scene_file(path, asset_root, builder_ptr, mode_override=-1):
+    """SceneFile::from_path against any rrt_builder; returns the camera."""
+    cam = Camera()
+    line = C.c_uint32(0)
+    rc = lib.rrt_parse_scene_file(path.encode(), asset_root.encode(), builder_ptr, C.byref(cam), mode_override, C.byref(line))
+    if rc < 0:
+        err = RrtError(rc, last_error())
+        err.line = line.value
+        raise err
+    return cam
+
+
+def parse_scene_text(text, asset_root, builder_ptr, mode_override=-1):
+    cam = Camera()
+    line = C.c_uint32(0)
+    rc = lib.rrt_parse_scene_text(text.encode(), asset_root.encode(), builder_ptr, C.byref(cam), mode_override, C.byref(line))
+    if rc < 0:
+        err = RrtError(rc, last_error())
+        err.line = line.value
+        raise err
+    return cam
+
+
+def quantise(values):
+    v = _f32(values)
+    out = np.zeros(v.shape, np.uint8)
+    lib.rrt_quantise(_fp(v), v.size, out.ctypes.data_as(_u8p))
+    return out
+
+
+class Scene:
+    """One Environment (scene.rs / photon_scene.rs) living behind the C ABI."""
+
+    def __init__(self, mode=MODE_SCENE, params=None, _handle=None):
+        self._h = _handle if _handle is not None else lib.rrt_scene_create(mode, C.byref(params) if params is not None else None)
+        if not self._h:
+            raise RrtError(ERR_INVALID, last_error())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.rrt_scene_destroy(h)
+
+    @classmethod
+    def load(cls, path, asset_root=REPO_ROOT, params=None, mode_override=-1):
+        scene = cls(MODE_SCENE, params)
+        cam = parse_scene_file(path, asset_root, scene.builder(), mode_override)
+        return scene, cam
+
+    @classmethod
+    def from_text(cls, text, asset_root=REPO_ROOT, params=None, mode_override=-1):
+        scene = cls(MODE_SCENE, params)
+        cam = parse_scene_text(text, asset_root, scene.builder(), mode_override)
+        return scene, cam
+
+    # -- construction ------------------------------------------------------------------
+    def builder(self):
+        return lib.rrt_scene_builder(self._h)
+
+    @property
+    def mode(self):
+        return lib.rrt_scene_get_mode(self._h)
+
+    def set_mode(self, mode):
+        check(lib.rrt_scene_set_mode(self._h, mode))
+
+    def set_params(self, params):
+        check(lib.rrt_scene_set_params(self._h, C.byref(params)))
+
+    def add_texture(self, width, height, maxval, samples):
+        return check(lib.rrt_add_texture(self._h, width, height, maxval, bytes(samples)))
+
+    def add_material(self, desc):
+        return check(lib.rrt_add_material(self._h, C.byref(desc)))
+
+    def object_define(self, desc):
+        return check(lib.rrt_object_define(self._h, C.byref(desc)))
+
+    def object_define_obj(self, path, material, smooth):
+        return check(lib.rrt_object_define_obj(self._h, path.encode(), material, int(smooth)))
+
+    def object_transform(self, handle, m16):
+        m = _f32(m16, (16,))
+        check(lib.rrt_object_transform(self._h, handle, _fp(m)))
+
+    def add_object(self, handle):
+        return check(lib.rrt_add_object(self._h, handle))
+
+    def add_light(self, desc):
+        return check(lib.rrt_add_light(self._h, C.byref(desc)))
+
+    def object_count(self):
+        return lib.rrt_object_count(self._h)
+
+    # -- passes --------------------------------------------------------------------------
+    def pre_render(self, seed=1):
+        check(lib.rrt_pre_render(self._h, seed))
+
+    def render(self, cam, y0=0, y1=None):
+        y1 = cam.height if y1 is None else y1
+        rows = y1 - y0
+        rgb = np.zeros((rows, cam.width, 3), np.float32)
+        depth = np.zeros((rows, cam.width), np.float32)
+        ids = np.zeros((rows, cam.width), np.uint32)
+        check(lib.rrt_render(self._h, C.byref(cam), y0, y1, _fp(rgb), _fp(depth), ids.ctypes.data_as(_u32p)))
+        return rgb, depth, ids
+
+    def render_device(self, cam, y0, y1, rgb_ptr, depth_ptr, id_ptr, stream=None):
+        check(lib.rrt_render_device(self._h, C.byref(cam), y0, y1, rgb_ptr, depth_ptr, id_ptr, stream))
+
+    def raytrace(self, origins, directions):
+        o, d = _f32(origins, (-1, 3)), _f32(directions, (-1, 3))
+        n = o.shape[0]
+        rgb = np.zeros((n, 3), np.float32)
+        depth = np.zeros(n, np.float32)
+        ids = np.zeros(n, np.uint32)
+        check(lib.rrt_raytrace(self._h, _fp(o), _fp(d), n, _fp(rgb), _fp(depth), ids.ctypes.data_as(_u32p)))
+        return rgb, depth, ids
+
+    def trace(self, origins, directions):
+        o, d = _f32(origins, (-1, 3)), _f32(directions, (-1, 3))
+        n = o.shape[0]
+        out = {
+            "object_id": np.zeros(n, np.uint32),
+            "prim_id": np.zeros(n, np.uint32),
+            "distance": np.zeros(n, np.float32),
+            "position": np.zeros((n, 3), np.float32),
+            "normal": np.zeros((n, 3), np.float32),
+            "uv": np.zeros((n, 2), np.float32),
+        }
+        check(
+            lib.rrt_trace(
+                self._h, _fp(o), _fp(d), n, out["object_id"].ctypes.data_as(_u32p), out["prim_id"].ctypes.data_as(_u32p),
+                _fp(out["distance"]), _fp(out["position"]), _fp(out["normal"]), _fp(out["uv"]),
+            )
+        )
+        return out
+
+    def shadowtrace(self, origins, directions, limits):
+        o, d, l = _f32(origins, (-1, 3)), _f32(directions, (-1, 3)), _f32(limits, (-1,))
+        occ = np.zeros(o.shape[0], np.uint8)
+        check(lib.rrt_shadowtrace(self._h, _fp(o), _fp(d), _fp(l), o.shape[0], occ.ctypes.data_as(_u8p)))
+        return occ
+
+    def photon_begin(self, seed):
+        check(lib.rrt_photon_begin(self._h, seed))
+
+    def photon_shoot(self, light, pass_, first, count):
+        check(lib.rrt_photon_shoot(self._h, light, pass_, first, count))
+
+    def photon_build(self):
+        check(lib.rrt_photon_build(self._h))
+
+    def stats(self):
+        st = Stats()
+        check(lib.rrt_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+
+def write_rgb_ppm(path, rgb):
+    a = _f32(rgb)
+    check(lib.rrt_write_rgb_ppm(path.encode(), _fp(a), a.shape[1], a.shape[0]))
+
+
+def write_depth_pgm(path, depth):
+    a = _f32(depth)
+    check(lib.rrt_write_depth_pgm(path.encode(), _fp(a), a.shape[1], a.shape[0]))

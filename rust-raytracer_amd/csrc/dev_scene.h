@@ -1,0 +1,145 @@
+// dev_scene.h — the flattened scene as it lives in HBM (SoA per primitive type) and the
+// per-ray records of the wavefront queues.  Shared by the host flattener and the gfx950 kernels.
+//
+// Layout rules: everything a ray touches for EVERY object (the "hot" arrays) is float4-packed so a
+// wave reads it with uniform (scalar-cache) or 16-B vector loads; everything needed only for the one
+// winning hit (uv frames, tangent frames, vertex normals) sits in separate "cold" arrays.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rrt.h"
+#include "rrt_math.h"
+
+namespace rrt {
+
+// ---- object programs ---------------------------------------------------------------------
+// A top-level object (one entry of Environment::objects()) is a post-order program: leaves push a
+// hit list, CSG ops pop two lists and push the merged one (csg_object.rs:39-108).  Plain objects
+// are one-instruction programs.
+enum Op : uint32_t {
+    OP_PLANE = 0,
+    OP_SPHERE = 1,
+    OP_CUBOID = 2,
+    OP_QUADRIC = 3,
+    OP_MESH = 4,
+    OP_CSG_UNION = 5,
+    OP_CSG_INTERSECTION = 6,
+    OP_CSG_DIFFERENCE = 7
+};
+struct Instr {
+    uint32_t op;
+    uint32_t index;  // into the array of its primitive type
+};
+struct ObjectRange {
+    uint32_t first, count;  // instruction range
+};
+
+// Plane::intersect needs only (normal, d): plane_object.rs:57-58
+struct PlaneCold {
+    f3 centre;
+    f3 u_unit, v_unit;     // plane_object.rs:96-97, ray independent
+    f3 tan_t, tan_b, tan_n;  // columns of to_tangent_space(right, normal), vector.rs:133-142
+    int32_t material;
+};
+struct CuboidHot {
+    float4 lo;  // corner - 1e-4 per axis (cuboid_object.rs:107-112); w = first plane index as int bits
+    float4 hi;  // (corner + size) + 1e-4
+};
+struct QuadricHot {
+    float4 abcd, efgh, ij_mat;  // ij_mat = (i, j, material bits, 0)
+};
+// Triangle as the traversal reads it: 64 B, one cache line pair per two triangles
+struct TriHot {
+    float4 a_nx;  // a.xyz, plane normal x
+    float4 b_ny;  // b.xyz, plane normal y
+    float4 c_nz;  // c.xyz, plane normal z
+    float4 d_pad; // plane d, 0, 0, 0
+};
+struct MeshInfo {
+    uint32_t tri_first, tri_count;
+    uint32_t node_first, node_count;
+    int32_t material;
+    uint32_t smooth;
+    uint32_t has_normals;
+    uint32_t nrm_first;  // first triangle of this mesh in tri_normals
+};
+// BVH2 node, 64 B: both children's boxes, so one node fetch decides both descents.
+// child < 0  -> leaf: ~child = first triangle slot (mesh-local, in BVH order), count in cnt
+struct BvhNode {
+    float4 lo_x_hi_x;  // l.lo.x, r.lo.x, l.hi.x, r.hi.x
+    float4 lo_y_hi_y;
+    float4 lo_z_hi_z;
+    int32_t child[2];
+    uint32_t cnt[2];
+};
+
+// ---- materials ----------------------------------------------------------------------------
+struct MatPart {
+    int32_t kind;  // rrt_material_kind (never COMPOUND)
+    float colour[3];
+    float ambient, shininess;
+    int32_t diffuse_tex, normal_tex;
+    float scale;
+    float wr, wt, ior;
+};
+struct DevMaterial {
+    int32_t is_compound;
+    int32_t n_parts;
+    MatPart parts[RRT_MAX_COMPOUND_PARTS];
+    int32_t global_part;  // index of the Global part (always last) or -1
+    int32_t nm_part;      // first part with a normal map (compound_material.rs:104-116) or -1
+    float w[4];           // behaviour_weight folded as the reference folds it
+    float surface_weight; // w[Absorb] + w[Diffuse] + w[Specular]   (photon_scene.rs:318-320)
+};
+struct DevTexture {
+    uint64_t offset;  // texel index into the u8x4 or u16x4 pool
+    uint32_t width, height;
+    uint32_t maxval;
+    uint32_t wide;  // 0: uchar4 pool, 1: ushort4 pool
+};
+struct DevLight {
+    int32_t kind;
+    f3 position, direction, intensity;
+};
+
+struct DevScene {
+    const Instr *instrs;
+    const ObjectRange *objects;
+    uint32_t n_objects;
+    uint32_t n_lights;
+    uint32_t max_program;  // longest object program
+    uint32_t has_csg;
+    const float4 *plane_hot;  // (normal.xyz, d)
+    const PlaneCold *plane_cold;
+    const float4 *sphere_hot;  // (centre.xyz, radius)
+    const int32_t *sphere_mat;
+    const CuboidHot *cuboid_hot;
+    const QuadricHot *quadric_hot;
+    const MeshInfo *meshes;
+    const TriHot *tris;        // BVH order
+    const uint32_t *tri_index; // BVH order -> original triangle index
+    const float *tri_normals;  // [orig tri][3][3], only for smooth meshes
+    const BvhNode *nodes;
+    const DevMaterial *materials;
+    const DevTexture *textures;
+    const uchar4 *texels8;
+    const ushort4 *texels16;
+    const DevLight *lights;
+};
+
+// ---- wavefront queue records -----------------------------------------------------------------
+// One queue per recursion level of Scene::raytrace (scene.rs:83-128, depth 0..5).
+struct LevelBuffers {
+    float4 *ray_o;   // origin.xyz, w = parent index (level 0: pixel index) as uint bits
+    float4 *ray_d;   // direction.xyz, w = child slot (0 reflection, 1 refraction) as uint bits
+    float4 *once;    // fold of the non-Global parts' compute_once, w = kr
+    float4 *glob;    // wr, wt, n_parts-or-0 (compound divisor, 0 = not compound), flags
+    float4 *lights;  // [n_lights][capacity]: per-light term already multiplied by intensity; w = lit flag
+    float4 *result;  // colour.rgb, depth
+    int2 *child;     // queue index of the reflection / refraction child at level+1, or -1
+    uint32_t *object_id;
+    uint32_t capacity;
+};
+enum NodeFlags : uint32_t { NF_HIT = 1, NF_HAS_GLOBAL = 2, NF_GLOBAL_ACTIVE = 4 /* depth < max_depth */ };
+
+}  // namespace rrt

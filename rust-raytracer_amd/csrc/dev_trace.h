@@ -1,0 +1,677 @@
+// dev_trace.h — gfx950 device functions: ray/object intersection as per-ray interval lists,
+// the nearest-entering-hit search, BVH traversal with per-lane LDS stacks, and lazy evaluation
+// of the winning hit's attributes.
+//
+// Every lane owns one ray; the loop over objects and each object's program is wave-uniform, so
+// scene data is fetched through the scalar cache and divergence is limited to data-dependent
+// branches (discriminant < 0, hit-list lengths, BVH descent).
+//
+// Exactness: distances, ids and hit attributes must equal the reference's f32 results bit for bit
+// (SURVEY.md §8a), so the formulas below keep the reference's operation order and nothing here may
+// be contracted into FMAs (the file is compiled with -ffp-contract=off).  The BVH only prunes:
+// its box test is deliberately conservative, the triangle test is the reference's.
+#pragma once
+#include "dev_scene.h"
+
+namespace rrt {
+
+#define RRT_LIST_CAP 6  // HitVec capacity, core/hit.rs:56
+#define RRT_F32_MAX 3.40282347e+38f
+#define RRT_INF __builtin_huge_valf()
+
+// hit-list entry meta word: bit 31 = entering (after CSG relabelling), bits 8..23 = instruction
+// index inside the object's program, bits 0..7 = sub-hit selector of that primitive
+#define META_ENTER 0x80000000u
+__device__ __forceinline__ uint32_t mk_meta(bool entering, uint32_t instr, uint32_t sub) {
+    return (entering ? META_ENTER : 0u) | (instr << 8) | sub;
+}
+
+// Per-block LDS views.  lists: [slot][entry][thread]; stack: [entry][thread] (aliases the lists:
+// meshes cannot be CSG leaves, so a lane never uses both at once).
+struct Lds {
+    float *lt;
+    uint32_t *lm;
+    int *stack;
+    uint32_t nthreads, tid;
+    __device__ __forceinline__ float &t(uint32_t slot, uint32_t e) { return lt[(slot * RRT_LIST_CAP + e) * nthreads + tid]; }
+    __device__ __forceinline__ uint32_t &m(uint32_t slot, uint32_t e) { return lm[(slot * RRT_LIST_CAP + e) * nthreads + tid]; }
+    __device__ __forceinline__ int &st(uint32_t e) { return stack[e * nthreads + tid]; }
+};
+
+struct Counters {
+    uint32_t nodes, tris, shadow, overflow;
+};
+
+struct TraceResult {
+    float t;
+    uint32_t object;  // 0xFFFFFFFF = miss
+    uint32_t instr;   // global instruction index of the leaf that produced the hit
+    uint32_t sub;     // sub-hit selector (triangle BVH slot for meshes)
+};
+
+// ---- primitives: distances only ------------------------------------------------------------------
+
+// Plane::intersect (plane_object.rs:54-113), distances and facing only.  Returns the hit count (0/2).
+__device__ __forceinline__ int plane_hits(float4 nd, f3 o, f3 d, float &t0, bool &e0, float &t1, bool &e1) {
+    f3 n = mk3(nd.x, nd.y, nd.z);
+    float U = dot3(n, o) + nd.w;
+    float V = dot3(n, d);
+    if (V == 0.0f) {
+        if (U >= 0.0f) {
+            t0 = -RRT_INF; e0 = true;
+            t1 = RRT_INF; e1 = false;
+            return 2;
+        }
+        return 0;
+    }
+    float t = U / -V;
+    if (V > 0.0f) {
+        t0 = -RRT_INF; e0 = true;
+        t1 = t; e1 = false;
+    } else {
+        t0 = t; e0 = true;
+        t1 = RRT_INF; e1 = false;
+    }
+    return 2;
+}
+
+// Sphere::intersect (sphere_object.rs:35-53): note the division by 2.0, not 2a
+__device__ __forceinline__ bool sphere_hits(float4 cr, f3 o, f3 d, float &t0, float &t1) {
+    f3 ro = o - mk3(cr.x, cr.y, cr.z);
+    float a = dot3(d, d);
+    float b = 2.0f * dot3(d, ro);
+    float c = dot3(ro, ro) - cr.w * cr.w;
+    float disc = b * b - 4.0f * a * c;
+    if (disc < 0.0f) return false;
+    float ds = sqrtf(disc);
+    t0 = (-b - ds) / 2.0f;
+    t1 = (-b + ds) / 2.0f;
+    return true;
+}
+
+// Quadratic::intersect (quadratic_object.rs:43-89)
+__device__ __forceinline__ bool quadric_hits(const QuadricHot &Q, f3 P, f3 D, float &t0, float &t1) {
+    float a = Q.abcd.x, b = Q.abcd.y, c = Q.abcd.z, d = Q.abcd.w;
+    float e = Q.efgh.x, f = Q.efgh.y, g = Q.efgh.z, h = Q.efgh.w;
+    float i = Q.ij_mat.x, j = Q.ij_mat.y;
+    float Aq = a * (D.x * D.x) + 2.0f * b * D.x * D.y + 2.0f * c * D.x * D.z + e * (D.y * D.y) + 2.0f * f * D.y * D.z +
+               h * (D.z * D.z);
+    float Bq = 2.0f * (a * P.x * D.x + b * (P.x * D.y + P.y * D.x) + c * (P.x * D.z + D.x * P.z) + d * D.x + e * P.y * D.y +
+                       f * (P.y * D.z + D.y * P.z) + g * D.y + h * P.z * D.z + i * D.z);
+    float Cq = a * (P.x * P.x) + 2.0f * b * P.x * P.y + 2.0f * c * P.x * P.z + 2.0f * d * P.x + e * (P.y * P.y) +
+               2.0f * f * P.y * P.z + 2.0f * g * P.y + h * (P.z * P.z) + 2.0f * i * P.z + j;
+    if (fabsf(Aq) == 0.0f) return false;
+    float disc = Bq * Bq - 4.0f * Aq * Cq;
+    if (disc < 0.0f) return false;
+    disc = sqrtf(disc);
+    float ta = (-Bq - disc) / (2.0f * Aq);
+    float tb = (-Bq + disc) / (2.0f * Aq);
+    if (ta > tb) {
+        t0 = tb;
+        t1 = ta;
+    } else {
+        t0 = ta;
+        t1 = tb;
+    }
+    return true;
+}
+
+// Cuboid::intersect (cuboid_object.rs:94-148): six half-space planes; the entering candidate with
+// the LARGEST distance and the exiting candidate with the SMALLEST distance survive (later planes
+// replace on ties).  sub = plane * 2 + position of the hit in that plane's list.
+__device__ __forceinline__ void cuboid_hits(const DevScene &S, const CuboidHot &C, f3 o, f3 d, bool &have_first, float &t_first,
+                                            uint32_t &sub_first, bool &have_back, float &t_back, uint32_t &sub_back) {
+    have_first = have_back = false;
+    t_first = t_back = 0.0f;
+    sub_first = sub_back = 0;
+    uint32_t p0 = __float_as_uint(C.lo.w);
+#pragma unroll
+    for (uint32_t p = 0; p < 6; p++) {
+        float4 nd = S.plane_hot[p0 + p];
+        f3 n = mk3(nd.x, nd.y, nd.z);
+        float U = dot3(n, o) + nd.w;
+        float V = dot3(n, d);
+        if (V == 0.0f) continue;  // both hits infinite: skipped at cuboid_object.rs:120-122
+        float t = U / -V;
+        bool entering = !(V > 0.0f);
+        f3 hp = o + d * t;
+        bool inside = hp.x >= C.lo.x && hp.x <= C.hi.x && hp.y >= C.lo.y && hp.y <= C.hi.y && hp.z >= C.lo.z && hp.z <= C.hi.z;
+        if (!inside) continue;
+        if (t < 0.0f) continue;
+        if (isinf(t)) continue;
+        if (entering) {
+            if (!(have_first && t_first > t)) {
+                have_first = true;
+                t_first = t;
+                sub_first = p * 2;  // list position 0 when V < 0
+            }
+        } else if (!(have_back && t_back < t)) {
+            have_back = true;
+            t_back = t;
+            sub_back = p * 2 + 1;  // list position 1 when V > 0
+        }
+    }
+}
+
+// ---- mesh: BVH2 traversal, per-lane stack in LDS ---------------------------------------------------
+
+// Triangle::intersect (triangle_object.rs:129-160) on the finite plane hit only (the infinite ones
+// can never be selected: see DESIGN.md "mesh semantics").  Returns true when the hit point passes
+// the same-side test; `entering` is the plane hit's facing.
+__device__ __forceinline__ bool tri_test(const TriHot &T, f3 o, f3 d, float &t, bool &entering) {
+    f3 n = mk3(T.a_nx.w, T.b_ny.w, T.c_nz.w);
+    float U = dot3(n, o) + T.d_pad.x;
+    float V = dot3(n, d);
+    if (V == 0.0f) return false;
+    t = U / -V;
+    entering = !(V > 0.0f);
+    f3 a = mk3(T.a_nx.x, T.a_nx.y, T.a_nx.z), b = mk3(T.b_ny.x, T.b_ny.y, T.b_ny.z), c = mk3(T.c_nz.x, T.c_nz.y, T.c_nz.z);
+    f3 p = o + d * t;
+    f3 ai = p - a, bi = p - b, ci = p - c;
+    f3 ab = b - a, bc = c - b, ca = a - c;  // Triangle::new, triangle_object.rs:51-53
+    f3 ab_n = cross3(ai, ab), bc_n = cross3(bi, bc), ca_n = cross3(ci, ca);
+    return dot3(ab_n, bc_n) > 0.0f && dot3(bc_n, ca_n) > 0.0f;
+}
+
+// Conservative ray/box slab test against both children of a node.  Three margins make sure the
+// BVH can only prune what the reference's exact test would reject anyway:
+//  * boxes are padded on the host by 2^-16 of their coordinate magnitude (bvh_build.cpp);
+//  * the box is grown by 2^-20 of the ray origin's magnitude (`op` = origin + e is used against the
+//    lower faces, `om` = origin - e against the upper faces), covering the rounding of o + d*t;
+//  * the [near, far] interval is widened by a relative 2^-20, covering the slab arithmetic itself.
+__device__ __forceinline__ void box2_test(const BvhNode &N, f3 op, f3 om, f3 inv, float tmax, bool &hit_l, bool &hit_r,
+                                          float &near_l, float &near_r) {
+    float lx0 = (N.lo_x_hi_x.x - op.x) * inv.x, lx1 = (N.lo_x_hi_x.z - om.x) * inv.x;
+    float rx0 = (N.lo_x_hi_x.y - op.x) * inv.x, rx1 = (N.lo_x_hi_x.w - om.x) * inv.x;
+    float ly0 = (N.lo_y_hi_y.x - op.y) * inv.y, ly1 = (N.lo_y_hi_y.z - om.y) * inv.y;
+    float ry0 = (N.lo_y_hi_y.y - op.y) * inv.y, ry1 = (N.lo_y_hi_y.w - om.y) * inv.y;
+    float lz0 = (N.lo_z_hi_z.x - op.z) * inv.z, lz1 = (N.lo_z_hi_z.z - om.z) * inv.z;
+    float rz0 = (N.lo_z_hi_z.y - op.z) * inv.z, rz1 = (N.lo_z_hi_z.w - om.z) * inv.z;
+    // fminf/fmaxf drop NaNs (0 * inf when the origin lies on a slab plane of a parallel ray)
+    float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
+    float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
+    float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
+    float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
+    const float k = 9.5367431640625e-7f;  // 2^-20
+    float lnc = ln - fabsf(ln) * k, lfc = lf + fabsf(lf) * k;
+    float rnc = rn - fabsf(rn) * k, rfc = rf + fabsf(rf) * k;
+    hit_l = lnc <= lfc && lfc >= 0.0f && lnc <= tmax;
+    hit_r = rnc <= rfc && rfc >= 0.0f && rnc <= tmax;
+    near_l = ln;
+    near_r = rn;
+}
+
+// PolyMesh::intersect (polymesh_object.rs:216-242): the closest hit of EITHER facing with t >= 0,
+// the lowest triangle index winning exact ties; only hits with t < tmax are reported (callers pass
+// the best distance so far: a farther mesh hit could not win anyway).  Returns the BVH slot.
+__device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &M, f3 o, f3 d, float tmax, Lds &lds, Counters &cnt,
+                                             float &best_t, uint32_t &best_slot, bool &best_entering) {
+    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float oe = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) * 9.5367431640625e-7f;
+    f3 op = o + mk3(oe, oe, oe), om = o - mk3(oe, oe, oe);
+    bool found = false;
+    float best = tmax;
+    uint32_t best_orig = 0xFFFFFFFFu;
+    best_slot = 0;
+    best_entering = false;
+    const BvhNode *nodes = S.nodes + M.node_first;
+    const TriHot *tris = S.tris + M.tri_first;
+    const uint32_t *orig = S.tri_index + M.tri_first;
+    int sp = 0;
+    int cur = 0;  // root
+    if (M.tri_count == 0) return false;
+    for (;;) {
+        if (cur >= 0) {
+            const BvhNode N = nodes[cur];
+            bool hl, hr;
+            float nl, nr;
+            box2_test(N, op, om, inv, best, hl, hr, nl, nr);
+            cnt.nodes += 2;
+            int cl = N.child[0], cr = N.child[1];
+            // leaves are encoded as negative ids; pack the leaf count next to it on the stack
+            int el = cl >= 0 ? cl : -(int)(((uint32_t)(~cl) << 4) | N.cnt[0]) - 1;
+            int er = cr >= 0 ? cr : -(int)(((uint32_t)(~cr) << 4) | N.cnt[1]) - 1;
+            if (hl && hr) {
+                bool left_first = !(nr < nl);
+                lds.st(sp++) = left_first ? er : el;
+                cur = left_first ? el : er;
+                continue;
+            } else if (hl) {
+                cur = el;
+                continue;
+            } else if (hr) {
+                cur = er;
+                continue;
+            }
+        } else {
+            uint32_t code = (uint32_t)(-(cur + 1));
+            uint32_t first = code >> 4, n = code & 15u;
+            for (uint32_t k = 0; k < n; k++) {
+                const TriHot T = tris[first + k];
+                float t;
+                bool ent;
+                cnt.tris++;
+                if (!tri_test(T, o, d, t, ent)) continue;
+                if (t < 0.0f) continue;
+                uint32_t oi = orig[first + k];
+                if (t < best || (found && t == best && oi < best_orig)) {
+                    found = true;
+                    best = t;
+                    best_orig = oi;
+                    best_slot = first + k;
+                    best_entering = ent;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = lds.st(--sp);
+    }
+    best_t = best;
+    return found;
+}
+
+// ---- CSG: per-ray interval lists (csg_object.rs:39-108) ---------------------------------------------
+
+__device__ __forceinline__ void csg_merge(uint32_t mode, Lds &lds, uint32_t sl, uint32_t nl, uint32_t sr, uint32_t nr, uint32_t so,
+                                          uint32_t &no, Counters &cnt) {
+    // action tables indexed by 4*L.entering + 2*R.entering + (L.d > R.d); 2 bits side/kind:
+    // 0 = ADrop, 1 = AEnter, 2 = AExit, 4 = BDrop, 5 = BEnter, 6 = BExit  (packed 4 bits per state)
+    //                        state:      7      6      5      4      3      2      1      0
+    const uint32_t tab_union = 0x51604240u;         // [ADrop,BDrop,AExit,BDrop,ADrop,BExit,AEnter,BEnter]
+    const uint32_t tab_intersection = 0x40415062u;  // [AExit,BExit,ADrop,BEnter,AEnter,BDrop,ADrop,BDrop]
+    const uint32_t tab_difference = 0x41406250u;    // [ADrop,BEnter,AExit,BExit,ADrop,BDrop,AEnter,BDrop]
+    uint32_t tab = mode == OP_CSG_UNION ? tab_union : (mode == OP_CSG_INTERSECTION ? tab_intersection : tab_difference);
+    uint32_t li = 0, ri = 0;
+    no = 0;
+    while (li < nl && ri < nr) {
+        float tl = lds.t(sl, li), tr = lds.t(sr, ri);
+        uint32_t ml = lds.m(sl, li), mr = lds.m(sr, ri);
+        uint32_t state = ((ml & META_ENTER) ? 4u : 0u) + ((mr & META_ENTER) ? 2u : 0u) + ((tl > tr) ? 1u : 0u);
+        uint32_t act = (tab >> (state * 4)) & 15u;
+        bool is_b = (act & 4u) != 0;
+        uint32_t kind = act & 3u;  // 0 drop, 1 enter, 2 exit
+        if (kind != 0) {
+            if (no >= RRT_LIST_CAP) {
+                cnt.overflow = 1;  // reference: panic "HitVec overflow"
+                return;
+            }
+            lds.t(so, no) = is_b ? tr : tl;
+            uint32_t mm = (is_b ? mr : ml) & ~META_ENTER;
+            lds.m(so, no) = mm | (kind == 1 ? META_ENTER : 0u);
+            no++;
+        }
+        if (is_b)
+            ri++;
+        else
+            li++;
+    }
+    if (mode != OP_CSG_INTERSECTION) {
+        for (; li < nl; li++) {
+            if (no >= RRT_LIST_CAP) {
+                cnt.overflow = 1;
+                return;
+            }
+            lds.t(so, no) = lds.t(sl, li);
+            lds.m(so, no) = lds.m(sl, li);
+            no++;
+        }
+    }
+    if (mode == OP_CSG_UNION) {
+        for (; ri < nr; ri++) {
+            if (no >= RRT_LIST_CAP) {
+                cnt.overflow = 1;
+                return;
+            }
+            lds.t(so, no) = lds.t(sr, ri);
+            lds.m(so, no) = lds.m(sr, ri);
+            no++;
+        }
+    }
+}
+
+// Leaf of a CSG program: write the primitive's hit list into LDS slot `slot`, return its length.
+__device__ __forceinline__ uint32_t leaf_list(const DevScene &S, Instr in, uint32_t local, f3 o, f3 d, Lds &lds, uint32_t slot) {
+    switch (in.op) {
+        case OP_PLANE: {
+            float t0, t1;
+            bool e0, e1;
+            if (plane_hits(S.plane_hot[in.index], o, d, t0, e0, t1, e1) == 0) return 0;
+            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(e0, local, 0);
+            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(e1, local, 1);
+            return 2;
+        }
+        case OP_SPHERE: {
+            float t0, t1;
+            if (!sphere_hits(S.sphere_hot[in.index], o, d, t0, t1)) return 0;
+            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(true, local, 0);
+            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(false, local, 1);
+            return 2;
+        }
+        case OP_QUADRIC: {
+            float t0, t1;
+            if (!quadric_hits(S.quadric_hot[in.index], o, d, t0, t1)) return 0;
+            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(true, local, 0);
+            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(false, local, 1);
+            return 2;
+        }
+        case OP_CUBOID: {
+            bool hf, hb;
+            float tf, tb;
+            uint32_t sf, sb;
+            cuboid_hits(S, S.cuboid_hot[in.index], o, d, hf, tf, sf, hb, tb, sb);
+            uint32_t n = 0;
+            if (hf) {
+                lds.t(slot, n) = tf; lds.m(slot, n) = mk_meta(true, local, sf);
+                n++;
+            }
+            if (hb) {
+                lds.t(slot, n) = tb; lds.m(slot, n) = mk_meta(false, local, sb);
+                n++;
+            }
+            return n;
+        }
+        default: return 0;
+    }
+}
+
+// Run an object's CSG program; the final list ends in LDS slot `out_slot` with length `out_n`.
+// The program is wave-uniform, so the slot stack is kept in scalar registers.
+__device__ __forceinline__ void csg_eval(const DevScene &S, ObjectRange R, f3 o, f3 d, Lds &lds, Counters &cnt, uint32_t &out_slot,
+                                         uint32_t &out_n) {
+    // slot ids of the live lists, packed 4 bits each (at most 7 live lists + 1 free)
+    uint32_t stack_slots = 0, sp = 0;
+    uint32_t free_mask = 0xFFu;  // free LDS slots
+    uint32_t len_l = 0;          // per-lane lengths of live lists, packed 4 bits each by stack position
+    for (uint32_t k = 0; k < R.count; k++) {
+        Instr in = S.instrs[R.first + k];
+        if (in.op < OP_CSG_UNION) {
+            uint32_t slot = __builtin_ctz(free_mask);
+            free_mask &= ~(1u << slot);
+            uint32_t n = leaf_list(S, in, k, o, d, lds, slot);
+            stack_slots |= slot << (sp * 4);
+            len_l = (len_l & ~(15u << (sp * 4))) | (n << (sp * 4));
+            sp++;
+        } else {
+            uint32_t sr = (stack_slots >> ((sp - 1) * 4)) & 15u, sl = (stack_slots >> ((sp - 2) * 4)) & 15u;
+            uint32_t nr = (len_l >> ((sp - 1) * 4)) & 15u, nl = (len_l >> ((sp - 2) * 4)) & 15u;
+            uint32_t so = __builtin_ctz(free_mask);
+            uint32_t no;
+            csg_merge(in.op, lds, sl, nl, sr, nr, so, no, cnt);
+            free_mask &= ~(1u << so);
+            free_mask |= (1u << sl) | (1u << sr);
+            sp -= 2;
+            stack_slots = (stack_slots & ~(0xFFu << (sp * 4))) | (so << (sp * 4));
+            len_l = (len_l & ~(0xFFu << (sp * 4))) | (no << (sp * 4));
+            sp++;
+        }
+    }
+    out_slot = stack_slots & 15u;
+    out_n = len_l & 15u;
+}
+
+// ---- Environment::trace (environment.rs:34-74) -----------------------------------------------------
+// First entering hit with distance >= 0 over all objects; strict `<` everywhere, so the first hit in
+// list order wins inside an object and the first object wins across objects.  `tmax_init` is
+// f32::MAX for trace; shadowtrace has its own loop below.
+__device__ __forceinline__ bool object_first_hit(const DevScene &S, uint32_t obj, f3 o, f3 d, float bound, Lds &lds, Counters &cnt,
+                                                 float &t_out, uint32_t &instr_out, uint32_t &sub_out) {
+    ObjectRange R = S.objects[obj];
+    if (R.count == 1) {
+        Instr in = S.instrs[R.first];
+        instr_out = R.first;
+        switch (in.op) {
+            case OP_PLANE: {
+                float t0, t1;
+                bool e0, e1;
+                if (plane_hits(S.plane_hot[in.index], o, d, t0, e0, t1, e1) == 0) return false;
+                // the only entering hit is list position 0 (finite when V < 0, -inf otherwise)
+                if (t0 < 0.0f) return false;
+                t_out = t0;
+                sub_out = 0;
+                return t0 < RRT_F32_MAX;
+            }
+            case OP_SPHERE: {
+                float t0, t1;
+                if (!sphere_hits(S.sphere_hot[in.index], o, d, t0, t1)) return false;
+                if (t0 < 0.0f) return false;
+                t_out = t0;
+                sub_out = 0;
+                return t0 < RRT_F32_MAX;
+            }
+            case OP_QUADRIC: {
+                float t0, t1;
+                if (!quadric_hits(S.quadric_hot[in.index], o, d, t0, t1)) return false;
+                if (t0 < 0.0f) return false;
+                t_out = t0;
+                sub_out = 0;
+                return t0 < RRT_F32_MAX;
+            }
+            case OP_CUBOID: {
+                bool hf, hb;
+                float tf, tb;
+                uint32_t sf, sb;
+                cuboid_hits(S, S.cuboid_hot[in.index], o, d, hf, tf, sf, hb, tb, sb);
+                if (!hf) return false;
+                t_out = tf;
+                sub_out = sf;
+                return tf < RRT_F32_MAX;
+            }
+            case OP_MESH: {
+                float t;
+                uint32_t slot;
+                bool ent;
+                if (!mesh_closest(S, S.meshes[in.index], o, d, bound, lds, cnt, t, slot, ent)) return false;
+                if (!ent) return false;  // a nearer back face hides farther front faces
+                t_out = t;
+                sub_out = slot;
+                return true;
+            }
+            default: return false;
+        }
+    }
+    uint32_t slot, n;
+    csg_eval(S, R, o, d, lds, cnt, slot, n);
+    bool have = false;
+    float best = RRT_F32_MAX;
+    for (uint32_t e = 0; e < n; e++) {
+        float t = lds.t(slot, e);
+        uint32_t m = lds.m(slot, e);
+        if (t < 0.0f) continue;
+        if (!(m & META_ENTER)) continue;
+        if (t < best) {
+            best = t;
+            have = true;
+            instr_out = R.first + ((m >> 8) & 0xFFFFu);
+            sub_out = m & 0xFFu;
+        }
+    }
+    t_out = best;
+    return have;
+}
+
+__device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, Counters &cnt, TraceResult &r) {
+    r.object = 0xFFFFFFFFu;
+    r.t = RRT_F32_MAX;
+    r.instr = 0;
+    r.sub = 0;
+    for (uint32_t obj = 0; obj < S.n_objects; obj++) {
+        float t;
+        uint32_t instr, sub;
+        if (!object_first_hit(S, obj, o, d, r.t, lds, cnt, t, instr, sub)) continue;
+        if (t < r.t) {
+            r.t = t;
+            r.object = obj;
+            r.instr = instr;
+            r.sub = sub;
+        }
+    }
+}
+
+// Scene::shadowtrace (scene.rs:65-79)
+__device__ __forceinline__ bool shadowtrace(const DevScene &S, f3 o, f3 d, float limit, Lds &lds, Counters &cnt) {
+    cnt.shadow++;
+    for (uint32_t obj = 0; obj < S.n_objects; obj++) {
+        float t;
+        uint32_t instr, sub;
+        // for meshes only hits below `limit` matter: the closest hit is either below it (and found)
+        // or cannot occlude
+        if (!object_first_hit(S, obj, o, d, limit, lds, cnt, t, instr, sub)) continue;
+        if (t > 0.0000001f && t < limit) return true;
+    }
+    return false;
+}
+
+// ---- lazy hit attributes -------------------------------------------------------------------------
+
+struct HitAttr {
+    f3 position, normal;
+    float u, v;
+    bool has_tex;
+    int32_t material;
+};
+
+// Image::get_uv / get_xy (texture.rs:105-119); texel = sample / maxval (texture.rs:89-93)
+__device__ __forceinline__ f3 tex_fetch(const DevScene &S, int32_t id, float u, float v) {
+    const DevTexture T = S.textures[id];
+    uint32_t x = sat_u32(floorf(rem_euclid_f(-u, 1.0f) * (float)(T.width - 1)));
+    float max_y = (float)T.width / (float)T.height;
+    uint32_t y = sat_u32(floorf(rem_euclid_f(-v, 1.0f) * max_y * (float)(T.height - 1)));
+    uint64_t idx = T.offset + (uint64_t)(y % T.height) * T.width + (x % T.width);
+    float mv = (float)T.maxval;
+    if (T.wide) {
+        ushort4 c = S.texels16[idx];
+        return mk3((float)c.x / mv, (float)c.y / mv, (float)c.z / mv);
+    }
+    uchar4 c = S.texels8[idx];
+    return mk3((float)c.x / mv, (float)c.y / mv, (float)c.z / mv);
+}
+
+// Material::normal (texture.rs:173-184 through compound_material.rs:104-116)
+__device__ __forceinline__ bool material_normal(const DevScene &S, int32_t material, float u, float v, f3 &out) {
+    const DevMaterial &M = S.materials[material];
+    if (M.nm_part < 0) return false;
+    const MatPart &P = M.parts[M.nm_part];
+    f3 c = tex_fetch(S, P.normal_tex, u * P.scale, v * P.scale);
+    out = norm3(c * 2.0f - mk3(1.0f, 1.0f, 1.0f));
+    return true;
+}
+
+// finite plane hit attributes (plane_object.rs:74-112); `list_pos` = position in the plane's hit list
+__device__ __forceinline__ void plane_attr(const DevScene &S, uint32_t plane, uint32_t list_pos, f3 o, f3 d, float t, HitAttr &h) {
+    float4 nd = S.plane_hot[plane];
+    const PlaneCold &C = S.plane_cold[plane];
+    f3 n = mk3(nd.x, nd.y, nd.z);
+    h.material = C.material;
+    float V = dot3(n, d);
+    bool finite_exit = (V > 0.0f) && list_pos == 1;
+    bool finite_enter = !(V == 0.0f) && !(V > 0.0f) && list_pos == 0;
+    if (finite_exit) {
+        h.position = o + d * t;
+        h.normal = -n;
+        h.has_tex = false;
+        h.u = h.v = 0.0f;
+    } else if (finite_enter) {
+        h.position = o + d * t;
+        f3 fc = h.position - C.centre;
+        h.u = dot3(fc, C.u_unit);
+        h.v = dot3(fc, C.v_unit);
+        h.has_tex = true;
+        h.normal = n;
+        f3 nm;
+        if (material_normal(S, C.material, h.u, h.v, nm)) h.normal = norm3(tbn_apply(C.tan_t, C.tan_b, C.tan_n, nm));
+    } else {  // Hit::infinity, core/hit.rs:37-52
+        h.position = mk3(0.0f, 0.0f, 0.0f);
+        h.normal = mk3(0.0f, 0.0f, 0.0f);
+        h.has_tex = false;
+        h.u = h.v = 0.0f;
+    }
+}
+
+__device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t instr_index, uint32_t sub, float t, HitAttr &h) {
+    Instr in = S.instrs[instr_index];
+    const float PI_F = 3.14159265358979323846f;
+    switch (in.op) {
+        case OP_PLANE: plane_attr(S, in.index, sub, o, d, t, h); break;
+        case OP_CUBOID: {
+            uint32_t p0 = __float_as_uint(S.cuboid_hot[in.index].lo.w);
+            plane_attr(S, p0 + (sub >> 1), sub & 1u, o, d, t, h);
+            break;
+        }
+        case OP_SPHERE: {  // sphere_object.rs:55-88
+            float4 cr = S.sphere_hot[in.index];
+            f3 c = mk3(cr.x, cr.y, cr.z);
+            h.material = S.sphere_mat[in.index];
+            h.position = o + d * t;
+            f3 n = norm3(h.position - c);
+            if (dot3(n, d) > 0.0f) n = -n;
+            float theta = atan2f(n.x, n.z) + PI_F;
+            float phi = acosf(-n.y);
+            h.u = theta / (2.0f * PI_F);
+            h.v = (PI_F - phi) / PI_F;
+            h.has_tex = true;
+            f3 nm;
+            if (material_normal(S, h.material, h.u, h.v, nm)) {
+                f3 tangent = norm3(cross3(mk3(1.0f, 0.0f, 0.0f), h.position - c));
+                nm = to_tangent_space3(nm, tangent, n);
+                n = norm3(nm);
+            }
+            h.normal = n;
+            break;
+        }
+        case OP_QUADRIC: {  // quadratic_object.rs:91-118
+            const QuadricHot &Q = S.quadric_hot[in.index];
+            h.material = (int32_t)__float_as_uint(Q.ij_mat.z);
+            f3 p = o + d * t;
+            h.position = p;
+            f3 n = norm3(mk3(Q.abcd.x * p.x + Q.abcd.y * p.y + Q.abcd.z * p.z + Q.abcd.w,
+                             Q.abcd.y * p.x + Q.efgh.x * p.y + Q.efgh.y * p.z + Q.efgh.z,
+                             Q.abcd.z * p.x + Q.efgh.y * p.y + Q.efgh.w * p.z + Q.ij_mat.x));
+            if (dot3(n, d) > 0.0f) n = -n;
+            h.normal = n;
+            h.has_tex = false;
+            h.u = h.v = 0.0f;
+            break;
+        }
+        case OP_MESH: {  // triangle_object.rs:85-160 for the winning triangle only
+            const MeshInfo &M = S.meshes[in.index];
+            const TriHot T = S.tris[M.tri_first + sub];
+            h.material = M.material;
+            f3 n = mk3(T.a_nx.w, T.b_ny.w, T.c_nz.w);
+            f3 a = mk3(T.a_nx.x, T.a_nx.y, T.a_nx.z), b = mk3(T.b_ny.x, T.b_ny.y, T.b_ny.z), c = mk3(T.c_nz.x, T.c_nz.y, T.c_nz.z);
+            f3 ab = b - a, bc = c - b, ca = a - c;
+            float V = dot3(n, d);
+            h.position = o + d * t;
+            if (V > 0.0f) {
+                h.normal = -n;
+                h.has_tex = false;
+                h.u = h.v = 0.0f;
+            } else {  // Plane::new_raw(a, up = ab, normal): plane_object.rs:92-105
+                f3 fc = h.position - a;
+                f3 v_unit = norm3(ab);
+                f3 u_unit = norm3(cross3(v_unit, n));
+                h.u = dot3(fc, u_unit);
+                h.v = dot3(fc, v_unit);
+                h.has_tex = true;
+                h.normal = n;
+                f3 nm;
+                if (material_normal(S, M.material, h.u, h.v, nm)) {
+                    f3 right = norm3(cross3(n, ab));
+                    h.normal = to_tangent_space3(nm, right, n);
+                }
+            }
+            if (M.smooth) {  // smoothen_hit, triangle_object.rs:98-125 (not flipped toward the ray)
+                f3 ai = h.position - a, bi = h.position - b, ci = h.position - c;
+                float gamma = len3(cross3(ai, ab));
+                float alpha = len3(cross3(bi, bc));
+                float beta = len3(cross3(ci, ca));
+                const float *vn = S.tri_normals + ((uint64_t)M.nrm_first + S.tri_index[M.tri_first + sub]) * 9;
+                f3 an = mk3(vn[0], vn[1], vn[2]), bn = mk3(vn[3], vn[4], vn[5]), cn = mk3(vn[6], vn[7], vn[8]);
+                h.normal = norm3(an * alpha + bn * beta + cn * gamma);
+            }
+            break;
+        }
+        default: break;
+    }
+}
+
+}  // namespace rrt

@@ -1,0 +1,71 @@
+// kernels.h — launch interface between the host runtime (runtime.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dev_scene.h"
+
+namespace rrt {
+
+struct DevCamera {
+    f3 position, right, up, lookat;
+    float fov;
+    uint32_t width, height;
+};
+
+// photon index in HBM (dev_photon.h)
+struct DevPhotonMap {
+    const float4 *pos_cell;  // [n] position.xyz, w unused (cell-sorted)
+    const float4 *incident;  // [n] normalised-again incident.xyz (photon_scene.rs:405), w unused
+    const float4 *intensity; // [n] intensity.rgb
+    const uint64_t *keys;    // [table_size] open-addressing hash table: cell key or ~0
+    const uint2 *ranges;     // [table_size] (first, count)
+    uint32_t table_mask;
+    uint32_t count;
+    float inv_cell;
+};
+
+enum StatSlot { ST_NODES = 0, ST_TRIS, ST_SHADOW, ST_GATHERED, ST_QUERIES, ST_CANDIDATES, ST_COUNT };
+
+struct TraceArgs {
+    DevScene S;
+    LevelBuffers cur, next;
+    DevCamera cam;
+    DevPhotonMap maps[2];
+    uint32_t count;       // rays in this level
+    uint32_t level;       // recursion depth of these rays
+    uint32_t max_depth;   // Scene: global_material.rs:72 (5); PhotonScene: max_vueon_depth
+    uint32_t mode;        // rrt_mode
+    uint32_t y0;          // first image row of the band being rendered
+    uint32_t pixel_base;  // first pixel (band-relative) of this chunk
+    uint32_t lds_slots;   // hit-list slots per lane (0 = scene has no CSG)
+    float gather_half_width;
+    uint32_t *next_count;
+    uint32_t *err;
+    unsigned long long *stats;
+    // level-0 outputs of the combine pass (any may be null)
+    float *out_rgb;
+    float *out_depth;
+    uint32_t *out_id;
+};
+
+void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream);
+void launch_combine(const TraceArgs &a, hipStream_t stream);
+
+struct BatchTraceArgs {
+    DevScene S;
+    const float *origins, *directions;  // [n][3]
+    const float *limits;                // shadowtrace only
+    uint32_t n;
+    uint32_t lds_slots;
+    uint32_t *object_id, *prim_id;
+    float *distance, *position, *normal, *uv;
+    uint8_t *occluded;
+    uint32_t *err;
+    unsigned long long *stats;
+};
+void launch_batch_trace(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream);
+void launch_batch_shadow(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream);
+// rays given explicitly (rrt_raytrace): fills level-0 ray buffers from host-style [n][3] arrays
+void launch_load_rays(const float *origins, const float *directions, uint32_t n, LevelBuffers lv, hipStream_t stream);
+
+}  // namespace rrt

@@ -1,0 +1,349 @@
+// kernels.hip — gfx950 kernels of the render pass.
+//
+//  k_trace_shade  one lane per ray of one recursion level: nearest-entering-hit search, hit
+//                 attributes, local shading terms (ambient part, per-light terms with inline shadow
+//                 rays, or the photon-map estimate in photon mode) and emission of the reflection /
+//                 refraction child rays into the next level's queue.  Children are appended with one
+//                 atomic per wave: a 64-bit ballot + lane-prefix popcount gives each lane its slot
+//                 (the compaction that keeps the next level's waves full).
+//  k_combine      bottom-up evaluation of the recursion (global_material.rs:100-107,
+//                 compound_material.rs:80-87, scene.rs:116-121 / photon_scene.rs:354-355) in the
+//                 reference's own operation order; level 0 writes the frame.
+//
+// Block = 256 threads = 4 waves; LDS per block = max(CSG hit lists, BVH stacks).
+#include "dev_photon.h"
+#include "dev_shade.h"
+#include "kernels.h"
+
+namespace rrt {
+
+#define RRT_BLOCK 256
+
+extern __shared__ float4 g_smem[];
+
+__device__ __forceinline__ Lds make_lds(uint32_t lds_slots) {
+    Lds l;
+    l.nthreads = RRT_BLOCK;
+    l.tid = threadIdx.x;
+    l.lt = reinterpret_cast<float *>(g_smem);
+    l.lm = reinterpret_cast<uint32_t *>(g_smem) + lds_slots * RRT_LIST_CAP * RRT_BLOCK;
+    l.stack = reinterpret_cast<int *>(g_smem);
+    return l;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void flush_counters(const Counters &cnt, unsigned long long gathered, unsigned long long queries,
+                                               unsigned long long candidates, unsigned long long *stats, uint32_t *err) {
+    unsigned long long n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), s = wave_sum(cnt.shadow);
+    unsigned long long g = wave_sum(gathered), q = wave_sum(queries), c = wave_sum(candidates);
+    if ((threadIdx.x & 63) == 0) {
+        if (n) atomicAdd(&stats[ST_NODES], n);
+        if (t) atomicAdd(&stats[ST_TRIS], t);
+        if (s) atomicAdd(&stats[ST_SHADOW], s);
+        if (g) atomicAdd(&stats[ST_GATHERED], g);
+        if (q) atomicAdd(&stats[ST_QUERIES], q);
+        if (c) atomicAdd(&stats[ST_CANDIDATES], c);
+    }
+    if (cnt.overflow) atomicOr(err, cnt.overflow);
+}
+
+// FullCamera::get_ray_pixel (full_camera.rs:61-81): d = M^T (fx-0.5, fy-0.5, fov), rows of M =
+// right, up, lookat; no aspect correction
+__device__ __forceinline__ void camera_ray(const DevCamera &C, uint32_t x, uint32_t y, f3 &o, f3 &d) {
+    float fx = ((float)x + 0.5f) / (float)C.width;
+    float fy = ((float)y + 0.5f) / (float)C.height;
+    f3 v = mk3(fx - 0.5f, fy - 0.5f, C.fov);
+    d = norm3(mk3(C.right.x * v.x + C.up.x * v.y + C.lookat.x * v.z, C.right.y * v.x + C.up.y * v.y + C.lookat.y * v.z,
+                  C.right.z * v.x + C.up.z * v.y + C.lookat.z * v.z));
+    o = C.position;
+}
+
+__global__ __launch_bounds__(RRT_BLOCK) void k_trace_shade(TraceArgs A) {
+    const DevScene &S = A.S;
+    Lds lds = make_lds(A.lds_slots);
+    uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
+    bool active = i < A.count;
+    Counters cnt = {0, 0, 0, 0};
+    unsigned long long gathered = 0, queries = 0, candidates = 0;
+    bool want_a = false, want_b = false;  // a: reflection child, b: refraction child
+    f3 ao = mk3(0, 0, 0), ad = mk3(0, 0, 0), bo = mk3(0, 0, 0), bd = mk3(0, 0, 0);
+
+    if (active) {
+        f3 o, d;
+        if (A.level == 0 && A.cam.width != 0) {
+            uint32_t pixel = A.pixel_base + i;
+            camera_ray(A.cam, pixel % A.cam.width, A.y0 + pixel / A.cam.width, o, d);
+        } else {
+            float4 ro = A.cur.ray_o[i], rd = A.cur.ray_d[i];
+            o = mk3(ro.x, ro.y, ro.z);
+            d = mk3(rd.x, rd.y, rd.z);
+        }
+        TraceResult tr;
+        trace(S, o, d, lds, cnt, tr);
+        if (tr.object == 0xFFFFFFFFu) {  // scene.rs:85-90 / photon_scene.rs:311-313
+            A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            A.cur.glob[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+            A.cur.object_id[i] = 0xFFFFFFFFu;
+        } else {
+            HitAttr h;
+            eval_hit(S, o, d, tr.instr, tr.sub, tr.t, h);
+            const DevMaterial &M = S.materials[h.material];
+            uint32_t flags = NF_HIT;
+            float kr = 0.0f;
+            A.cur.object_id[i] = tr.object;
+            A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, tr.t);  // depth = hit.distance (scene.rs:124-127)
+            if (A.mode == RRT_MODE_SCENE) {
+                f3 once = material_once_pre(S, M, h, cnt);
+                float wr = 0.0f, wt = 0.0f;
+                if (M.global_part >= 0) {  // GlobalMaterial::compute_once, global_material.rs:71-98
+                    const MatPart &G = M.parts[M.global_part];
+                    flags |= NF_HAS_GLOBAL;
+                    wr = G.wr;
+                    wt = G.wt;
+                    if (A.level < A.max_depth) {
+                        flags |= NF_GLOBAL_ACTIVE;
+                        if (wr > 0.0f) {
+                            ad = norm3(reflect3(h.normal, d));
+                            ao = h.position + ad * 0.0001f;
+                            want_a = true;
+                        }
+                        if (wt > 0.0f) want_b = global_refraction(G, h, true, d, bo, bd, kr);
+                    }
+                }
+                A.cur.once[i] = make_float4(once.x, once.y, once.z, kr);
+                A.cur.glob[i] = make_float4(wr, wt, M.is_compound ? (float)M.n_parts : 0.0f, __uint_as_float(flags));
+                // scene.rs:96-122
+                for (uint32_t l = 0; l < S.n_lights; l++) {
+                    const DevLight L = S.lights[l];
+                    f3 viewer = -norm3(h.position);  // eye assumed at the origin
+                    f3 ldir;
+                    bool lit = light_direction(L, h.position, ldir);
+                    if (lit && dot3(ldir, h.normal) > 0.0f) lit = false;
+                    if (lit) {
+                        f3 sd = -ldir;
+                        f3 so = h.position + sd * 0.0001f;
+                        if (shadowtrace(S, so, sd, len3(ldir), lds, cnt)) lit = false;
+                    }
+                    f3 term = mk3(0.0f, 0.0f, 0.0f);
+                    if (lit) term = material_per_light(S, M, h, viewer, ldir, cnt) * light_intensity(L, h.position);
+                    A.cur.lights[(size_t)l * A.cur.capacity + i] = make_float4(term.x, term.y, term.z, lit ? 1.0f : 0.0f);
+                }
+            } else {  // PhotonScene::vueontrace, photon_scene.rs:309-361
+                float sw = M.surface_weight, rw = M.w[3];
+                f3 surface = mk3(0.0f, 0.0f, 0.0f);
+                if (sw > 0.0f) {
+                    f3 inc, inten;
+                    queries += 2;
+                    if (average_photon_at(A.maps, h.position, A.gather_half_width, inc, inten, gathered, candidates))
+                        surface = material_render_vueon(S, M, h, inc, inten, -d, cnt);
+                }
+                bool deeper = A.level + 1 <= A.max_depth;
+                if (rw > 0.0f && deeper) {
+                    ao = h.position + h.normal * 0.0001f;
+                    ad = norm3(reflect3(h.normal, d));
+                    want_a = true;
+                }
+                if (M.global_part >= 0) {
+                    f3 to, td;
+                    float k;
+                    if (global_refraction(M.parts[M.global_part], h, true, d, to, td, k) && deeper) {
+                        bo = to + td * 0.0001f;
+                        bd = td;
+                        want_b = true;
+                    }
+                }
+                A.cur.once[i] = make_float4(surface.x, surface.y, surface.z, 0.0f);
+                A.cur.glob[i] = make_float4(rw, sw, 0.0f, __uint_as_float(flags));
+            }
+        }
+    }
+
+    // ---- wave-compacted append of the child rays to the next level's queue ----
+    unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
+    uint32_t total = __popcll(ma) + __popcll(mb);
+    int2 child = make_int2(-1, -1);
+    if (total) {
+        uint32_t lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(A.next_count, total);
+        base = __shfl(base, 0, 64);
+        unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+        uint32_t off = base + __popcll(ma & below) + __popcll(mb & below);
+        if (want_a) {
+            child.x = (int)off;
+            A.next.ray_o[off] = make_float4(ao.x, ao.y, ao.z, __uint_as_float(i));
+            A.next.ray_d[off] = make_float4(ad.x, ad.y, ad.z, __uint_as_float(0u));
+            off++;
+        }
+        if (want_b) {
+            child.y = (int)off;
+            A.next.ray_o[off] = make_float4(bo.x, bo.y, bo.z, __uint_as_float(i));
+            A.next.ray_d[off] = make_float4(bd.x, bd.y, bd.z, __uint_as_float(1u));
+        }
+    }
+    if (active) A.cur.child[i] = child;
+    flush_counters(cnt, gathered, queries, candidates, A.stats, A.err);
+}
+
+__global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
+    uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
+    if (i >= A.count) return;
+    float4 g = A.cur.glob[i];
+    uint32_t flags = __float_as_uint(g.w);
+    float4 res = A.cur.result[i];
+    f3 colour = mk3(0.0f, 0.0f, 0.0f);
+    if (flags & NF_HIT) {
+        float4 on = A.cur.once[i];
+        f3 once = mk3(on.x, on.y, on.z);
+        int2 ch = A.cur.child[i];
+        f3 ca = mk3(0, 0, 0), cb = mk3(0, 0, 0);
+        if (ch.x >= 0) {
+            float4 r = A.next.result[ch.x];
+            ca = mk3(r.x, r.y, r.z);
+        }
+        if (ch.y >= 0) {
+            float4 r = A.next.result[ch.y];
+            cb = mk3(r.x, r.y, r.z);
+        }
+        if (A.mode == RRT_MODE_SCENE) {
+            float wr = g.x, wt = g.y, div = g.z, kr = on.w;
+            f3 total = once;
+            if (flags & NF_HAS_GLOBAL) {
+                f3 gl = mk3(0.0f, 0.0f, 0.0f);
+                if (flags & NF_GLOBAL_ACTIVE) {  // global_material.rs:100-107
+                    bool have_a = ch.x >= 0, have_b = ch.y >= 0;
+                    f3 ra = ca * wr, rb = cb * wt;
+                    if (have_a && have_b)
+                        gl = (ra * kr) + (rb * (1.0f - kr));
+                    else if (have_a)
+                        gl = ra;
+                    else if (have_b)
+                        gl = rb;
+                }
+                total = (div != 0.0f) ? once + gl : gl;
+            }
+            if (div != 0.0f) total = total / div;  // compound_material.rs:86
+            colour = total;
+            for (uint32_t l = 0; l < A.S.n_lights; l++) {  // scene.rs:116-121
+                float4 t = A.cur.lights[(size_t)l * A.cur.capacity + i];
+                if (t.w != 0.0f) colour = colour + mk3(t.x, t.y, t.z);
+            }
+        } else {  // photon_scene.rs:336-355
+            float rw = g.x, sw = g.y;
+            f3 refl = mk3(0, 0, 0), refr = mk3(0, 0, 0);
+            if (ch.x >= 0) refl = ca * rw;
+            if (ch.y >= 0) refr = cb * rw;
+            colour = once + refl + refr;
+            colour = colour / (sw + rw + rw);
+        }
+    }
+    A.cur.result[i] = make_float4(colour.x, colour.y, colour.z, res.w);
+    if (A.level == 0) {
+        uint32_t pixel = A.pixel_base + i;
+        if (A.out_rgb) {
+            A.out_rgb[(size_t)pixel * 3 + 0] = colour.x;
+            A.out_rgb[(size_t)pixel * 3 + 1] = colour.y;
+            A.out_rgb[(size_t)pixel * 3 + 2] = colour.z;
+        }
+        if (A.out_depth) A.out_depth[pixel] = res.w;
+        if (A.out_id) A.out_id[pixel] = A.cur.object_id[i];
+    }
+}
+
+// ---- batched Environment::trace / Scene::shadowtrace for the C ABI's test entry points ----
+__global__ __launch_bounds__(RRT_BLOCK) void k_batch_trace(BatchTraceArgs A) {
+    Lds lds = make_lds(A.lds_slots);
+    uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
+    Counters cnt = {0, 0, 0, 0};
+    if (i < A.n) {
+        f3 o = mk3(A.origins[i * 3], A.origins[i * 3 + 1], A.origins[i * 3 + 2]);
+        f3 d = mk3(A.directions[i * 3], A.directions[i * 3 + 1], A.directions[i * 3 + 2]);
+        TraceResult tr;
+        trace(A.S, o, d, lds, cnt, tr);
+        bool ok = tr.object != 0xFFFFFFFFu;
+        HitAttr h;
+        h.position = h.normal = mk3(0, 0, 0);
+        h.u = h.v = 0.0f;
+        h.has_tex = false;
+        uint32_t prim = 0;
+        if (ok) {
+            eval_hit(A.S, o, d, tr.instr, tr.sub, tr.t, h);
+            Instr in = A.S.instrs[tr.instr];
+            ObjectRange R = A.S.objects[tr.object];
+            if (in.op == OP_MESH) {
+                const MeshInfo &M = A.S.meshes[in.index];
+                prim = A.S.tri_index[M.tri_first + tr.sub];
+            } else if (R.count > 1) {  // leaf number in post-order
+                uint32_t leaf = 0;
+                for (uint32_t k = R.first; k < tr.instr; k++)
+                    if (A.S.instrs[k].op < OP_CSG_UNION) leaf++;
+                prim = leaf;
+            } else if (in.op == OP_CUBOID) {
+                prim = tr.sub;
+            }
+        }
+        if (A.object_id) A.object_id[i] = tr.object;
+        if (A.prim_id) A.prim_id[i] = prim;
+        if (A.distance) A.distance[i] = ok ? tr.t : 0.0f;
+        if (A.position) {
+            A.position[i * 3] = h.position.x; A.position[i * 3 + 1] = h.position.y; A.position[i * 3 + 2] = h.position.z;
+        }
+        if (A.normal) {
+            A.normal[i * 3] = h.normal.x; A.normal[i * 3 + 1] = h.normal.y; A.normal[i * 3 + 2] = h.normal.z;
+        }
+        if (A.uv) {
+            float nanv = __uint_as_float(0x7FC00000u);
+            A.uv[i * 2] = (ok && h.has_tex) ? h.u : nanv;
+            A.uv[i * 2 + 1] = (ok && h.has_tex) ? h.v : nanv;
+        }
+    }
+    flush_counters(cnt, 0, 0, 0, A.stats, A.err);
+}
+
+__global__ __launch_bounds__(RRT_BLOCK) void k_batch_shadow(BatchTraceArgs A) {
+    Lds lds = make_lds(A.lds_slots);
+    uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
+    Counters cnt = {0, 0, 0, 0};
+    if (i < A.n) {
+        f3 o = mk3(A.origins[i * 3], A.origins[i * 3 + 1], A.origins[i * 3 + 2]);
+        f3 d = mk3(A.directions[i * 3], A.directions[i * 3 + 1], A.directions[i * 3 + 2]);
+        A.occluded[i] = shadowtrace(A.S, o, d, A.limits[i], lds, cnt) ? 1 : 0;
+    }
+    flush_counters(cnt, 0, 0, 0, A.stats, A.err);
+}
+
+__global__ void k_load_rays(const float *origins, const float *directions, uint32_t n, LevelBuffers lv) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    lv.ray_o[i] = make_float4(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2], __uint_as_float(i));
+    lv.ray_d[i] = make_float4(directions[i * 3], directions[i * 3 + 1], directions[i * 3 + 2], 0.0f);
+}
+
+static inline uint32_t blocks_for(uint32_t n) { return (n + RRT_BLOCK - 1) / RRT_BLOCK; }
+
+void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream) {
+    if (a.count == 0) return;
+    hipLaunchKernelGGL(k_trace_shade, dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes, stream, a);
+}
+void launch_combine(const TraceArgs &a, hipStream_t stream) {
+    if (a.count == 0) return;
+    hipLaunchKernelGGL(k_combine, dim3(blocks_for(a.count)), dim3(RRT_BLOCK), 0, stream, a);
+}
+void launch_batch_trace(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream) {
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(k_batch_trace, dim3(blocks_for(a.n)), dim3(RRT_BLOCK), lds_bytes, stream, a);
+}
+void launch_batch_shadow(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream) {
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(k_batch_shadow, dim3(blocks_for(a.n)), dim3(RRT_BLOCK), lds_bytes, stream, a);
+}
+void launch_load_rays(const float *origins, const float *directions, uint32_t n, LevelBuffers lv, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_load_rays, dim3(blocks_for(n)), dim3(RRT_BLOCK), 0, stream, origins, directions, n, lv);
+}
+
+}  // namespace rrt

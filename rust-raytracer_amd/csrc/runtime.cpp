@@ -1,0 +1,906 @@
+// runtime.cpp — scene flattening into HBM, the wavefront render loop, and the C ABI of include/rrt.h.
+#include "runtime.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+using namespace rrt;
+
+rrt_scene::~rrt_scene() {
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    if (host_pinned) (void)hipHostFree(host_pinned);
+}
+
+namespace rrt {
+
+int LevelStorage::ensure(uint32_t n, uint32_t n_lights, bool need_rays) {
+    if (n == 0) n = 1;
+    if (n <= capacity) return RRT_OK;
+    uint32_t cap = n + n / 8 + 256;
+    int rc = RRT_OK;
+    if (need_rays) {
+        if ((rc = ray_o.ensure(cap))) return rc;
+        if ((rc = ray_d.ensure(cap))) return rc;
+    }
+    if ((rc = once.ensure(cap))) return rc;
+    if ((rc = glob.ensure(cap))) return rc;
+    if ((rc = lights.ensure((size_t)cap * std::max(1u, n_lights)))) return rc;
+    if ((rc = result.ensure(cap))) return rc;
+    if ((rc = child.ensure(cap))) return rc;
+    if ((rc = object_id.ensure(cap))) return rc;
+    capacity = cap;
+    return RRT_OK;
+}
+LevelBuffers LevelStorage::view() const {
+    LevelBuffers v;
+    v.ray_o = ray_o.p;
+    v.ray_d = ray_d.p;
+    v.once = once.p;
+    v.glob = glob.p;
+    v.lights = lights.p;
+    v.result = result.p;
+    v.child = child.p;
+    v.object_id = object_id.p;
+    v.capacity = capacity;
+    return v;
+}
+DevPhotonMap PhotonIndex::view() const {
+    DevPhotonMap m;
+    m.pos_cell = pos.p;
+    m.incident = dir.p;
+    m.intensity = rgb.p;
+    m.keys = keys.p;
+    m.ranges = ranges.p;
+    m.table_mask = table_size ? table_size - 1 : 0;
+    m.count = (uint32_t)count;
+    m.inv_cell = inv_cell;
+    return m;
+}
+
+// ---- flattening ---------------------------------------------------------------------------------
+namespace {
+
+struct Flat {
+    std::vector<Instr> instrs;
+    std::vector<ObjectRange> objects;
+    std::vector<float4> plane_hot;
+    std::vector<PlaneCold> plane_cold;
+    std::vector<float4> sphere_hot;
+    std::vector<int32_t> sphere_mat;
+    std::vector<CuboidHot> cuboid_hot;
+    std::vector<QuadricHot> quadric_hot;
+    std::vector<MeshInfo> meshes;
+    std::vector<TriHot> tris;
+    std::vector<uint32_t> tri_index;
+    std::vector<float> tri_normals;
+    std::vector<BvhNode> nodes;
+    uint32_t bvh_depth = 0;
+    uint64_t flops = 0;
+};
+
+uint32_t add_plane(Flat &F, f3 point, f3 up, f3 normal, float d, int material) {
+    uint32_t idx = (uint32_t)F.plane_hot.size();
+    F.plane_hot.push_back(make_float4(normal.x, normal.y, normal.z, d));
+    PlaneCold c;
+    c.centre = point;
+    c.v_unit = norm3(up);                         // plane_object.rs:96
+    c.u_unit = norm3(cross3(c.v_unit, normal));   // plane_object.rs:97
+    f3 right = norm3(cross3(normal, up));         // plane_object.rs:103
+    c.tan_t = norm3(right);                       // vector.rs:134-136
+    c.tan_n = norm3(normal);
+    c.tan_b = cross3(c.tan_n, c.tan_t);
+    c.material = material;
+    F.plane_cold.push_back(c);
+    return idx;
+}
+
+void emit(Flat &F, const HostObject &o) {
+    switch (o.kind) {
+        case RRT_OBJ_PLANE: {
+            uint32_t idx = add_plane(F, o.p0, o.p1, o.p2, o.d, o.material);
+            F.instrs.push_back({OP_PLANE, idx});
+            F.flops += 18;
+            break;
+        }
+        case RRT_OBJ_SPHERE:
+            F.instrs.push_back({OP_SPHERE, (uint32_t)F.sphere_hot.size()});
+            F.sphere_hot.push_back(make_float4(o.p0.x, o.p0.y, o.p0.z, o.radius));
+            F.sphere_mat.push_back(o.material);
+            F.flops += 35;
+            break;
+        case RRT_OBJ_CUBOID: {  // cuboid_object.rs:58-90, plane order = CuboidPlanes::iter (:27-37)
+            f3 corner = o.p0, size = o.p1;
+            f3 fdl = corner;
+            f3 ful = corner + mk3(0.0f, size.y, 0.0f);
+            f3 bdl = corner + mk3(0.0f, 0.0f, size.z);
+            f3 bdr = corner + mk3(size.x, 0.0f, size.z);
+            f3 up = mk3(0, 1, 0), down = mk3(0, -1, 0), left = mk3(-1, 0, 0), right = mk3(1, 0, 0), fw = mk3(0, 0, 1), bw = mk3(0, 0, -1);
+            struct {
+                f3 pt, up, n;
+            } pl[6] = {{fdl, up, left}, {bdr, up, right}, {ful, fw, up}, {fdl, fw, down}, {fdl, up, bw}, {bdl, down, fw}};
+            uint32_t first = 0;
+            for (int k = 0; k < 6; k++) {
+                uint32_t idx = add_plane(F, pl[k].pt, pl[k].up, pl[k].n, -dot3(pl[k].n, pl[k].pt), o.material);
+                if (k == 0) first = idx;
+            }
+            CuboidHot c;
+            c.lo = make_float4(corner.x - 0.0001f, corner.y - 0.0001f, corner.z - 0.0001f, 0.0f);
+            c.hi = make_float4(corner.x + size.x + 0.0001f, corner.y + size.y + 0.0001f, corner.z + size.z + 0.0001f, 0.0f);
+            memcpy(&c.lo.w, &first, 4);
+            F.instrs.push_back({OP_CUBOID, (uint32_t)F.cuboid_hot.size()});
+            F.cuboid_hot.push_back(c);
+            F.flops += 6 * 18 + 6 * 12;
+            break;
+        }
+        case RRT_OBJ_QUADRATIC: {
+            QuadricHot q;
+            q.abcd = make_float4(o.q[0], o.q[1], o.q[2], o.q[3]);
+            q.efgh = make_float4(o.q[4], o.q[5], o.q[6], o.q[7]);
+            q.ij_mat = make_float4(o.q[8], o.q[9], 0.0f, 0.0f);
+            int32_t m = o.material;
+            memcpy(&q.ij_mat.z, &m, 4);
+            F.instrs.push_back({OP_QUADRIC, (uint32_t)F.quadric_hot.size()});
+            F.quadric_hot.push_back(q);
+            F.flops += 95;
+            break;
+        }
+        case RRT_OBJ_MESH: {
+            uint32_t n = (uint32_t)(o.tri_pos.size() / 9);
+            MeshInfo mi;
+            mi.tri_first = (uint32_t)F.tris.size();
+            mi.tri_count = n;
+            mi.node_first = (uint32_t)F.nodes.size();
+            mi.material = o.material;
+            mi.smooth = o.smooth ? 1u : 0u;
+            mi.has_normals = o.tri_nrm.empty() ? 0u : 1u;
+            mi.nrm_first = (uint32_t)(F.tri_normals.size() / 9);
+            std::vector<uint32_t> order;
+            std::vector<BvhNode> nodes;
+            uint32_t depth = 0;
+            build_bvh(o.tri_pos.data(), n, order, nodes, depth);
+            F.bvh_depth = std::max(F.bvh_depth, depth);
+            mi.node_count = (uint32_t)nodes.size();
+            F.nodes.insert(F.nodes.end(), nodes.begin(), nodes.end());
+            for (uint32_t k = 0; k < n; k++) {
+                const float *p = o.tri_pos.data() + (size_t)order[k] * 9;
+                f3 a = mk3(p[0], p[1], p[2]), b = mk3(p[3], p[4], p[5]), c = mk3(p[6], p[7], p[8]);
+                f3 ab = b - a, bc = c - b;                  // triangle_object.rs:51-52
+                f3 nrm = norm3(cross3(ab, bc));             // triangle_object.rs:85-89
+                float d = -dot3(nrm, a);                    // plane_object.rs:37
+                TriHot t;
+                t.a_nx = make_float4(a.x, a.y, a.z, nrm.x);
+                t.b_ny = make_float4(b.x, b.y, b.z, nrm.y);
+                t.c_nz = make_float4(c.x, c.y, c.z, nrm.z);
+                t.d_pad = make_float4(d, 0.0f, 0.0f, 0.0f);
+                F.tris.push_back(t);
+                F.tri_index.push_back(order[k]);
+            }
+            F.tri_normals.insert(F.tri_normals.end(), o.tri_nrm.begin(), o.tri_nrm.end());
+            F.instrs.push_back({OP_MESH, (uint32_t)F.meshes.size()});
+            F.meshes.push_back(mi);
+            break;
+        }
+        case RRT_OBJ_CSG:
+            emit(F, *o.left);
+            emit(F, *o.right);
+            F.instrs.push_back({(uint32_t)(OP_CSG_UNION + o.csg_mode), 0u});
+            break;
+    }
+}
+
+int flatten_materials(rrt_scene *s, std::vector<DevMaterial> &out, bool &reflective) {
+    reflective = false;
+    auto part_of = [](const rrt_material_desc &d) {
+        MatPart p;
+        memset(&p, 0, sizeof(p));
+        p.kind = d.kind;
+        for (int i = 0; i < 3; i++) p.colour[i] = d.colour[i];
+        p.ambient = d.ambient;
+        p.shininess = d.shininess;
+        p.diffuse_tex = d.diffuse_tex;
+        p.normal_tex = d.normal_tex;
+        p.scale = d.scale;
+        p.wr = d.reflect_weight;
+        p.wt = d.refract_weight;
+        p.ior = d.ior;
+        return p;
+    };
+    for (const rrt_material_desc &d : s->materials) {
+        DevMaterial m;
+        memset(&m, 0, sizeof(m));
+        m.global_part = -1;
+        m.nm_part = -1;
+        if (d.kind == RRT_MAT_COMPOUND) {
+            m.is_compound = 1;
+            m.n_parts = d.n_parts;
+            for (int i = 0; i < d.n_parts; i++) m.parts[i] = part_of(s->materials[d.parts[i]]);
+        } else {
+            m.is_compound = 0;
+            m.n_parts = 1;
+            m.parts[0] = part_of(d);
+        }
+        float w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < m.n_parts; i++) {
+            const MatPart &p = m.parts[i];
+            if (p.kind == RRT_MAT_GLOBAL) {
+                m.global_part = i;
+                if (p.wr > 0.0f || p.wt > 0.0f) reflective = true;
+            }
+            if (p.kind == RRT_MAT_TEXTURE && p.normal_tex >= 0 && m.nm_part < 0) m.nm_part = i;
+            // material.rs:54-61 / global_material.rs:116-123
+            float pw[4] = {0.6f, 0.3f, 0.1f, 0.0f};
+            if (p.kind == RRT_MAT_GLOBAL) {
+                pw[0] = pw[1] = pw[2] = 0.0f;
+                pw[3] = 1.0f;
+            }
+            for (int b = 0; b < 4; b++) w[b] = m.is_compound ? w[b] + pw[b] : pw[b];  // compound_material.rs:124-128
+        }
+        for (int b = 0; b < 4; b++) m.w[b] = m.is_compound ? w[b] / (float)m.n_parts : w[b];
+        m.surface_weight = m.w[0] + m.w[1] + m.w[2];  // photon_scene.rs:318-320
+        out.push_back(m);
+    }
+    return RRT_OK;
+}
+
+}  // namespace
+
+int flatten_scene(rrt_scene *s) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(RRT_ERR_DEVICE, "no HIP device: librrt has no CPU fallback");
+    Flat F;
+    uint32_t max_stack = 0, max_prog = 1;
+    bool has_csg = false;
+    for (auto &o : s->objects) {
+        ObjectRange r;
+        r.first = (uint32_t)F.instrs.size();
+        emit(F, *o);
+        r.count = (uint32_t)F.instrs.size() - r.first;
+        F.objects.push_back(r);
+        max_prog = std::max(max_prog, r.count);
+        if (r.count > 1) {
+            has_csg = true;
+            if (r.count > 0xFFFF) return fail(RRT_ERR_LIMIT, "CSG program longer than 65535 instructions");
+            uint32_t sp = 0;
+            for (uint32_t k = 0; k < r.count; k++) {
+                if (F.instrs[r.first + k].op < OP_CSG_UNION)
+                    sp++;
+                else
+                    sp--;
+                max_stack = std::max(max_stack, sp);
+            }
+        }
+    }
+    DeviceScene &D = s->dev;
+    D.lds_slots = has_csg ? max_stack + 1 : 0;
+    if (D.lds_slots > 8) return fail(RRT_ERR_LIMIT, "CSG tree needs more than 7 live hit lists");
+    D.bvh_stack = F.bvh_depth ? F.bvh_depth + 1 : 0;
+    size_t list_bytes = (size_t)D.lds_slots * 6 /* HitVec capacity */ * 256 * 8;
+    size_t stack_bytes = (size_t)D.bvh_stack * 256 * 4;
+    D.lds_bytes = std::max(list_bytes, stack_bytes);
+    if (D.lds_bytes > 160 * 1024) return fail(RRT_ERR_LIMIT, "per-block LDS need exceeds 160 KiB (BVH too deep)");
+    D.flops_per_trace = F.flops;
+
+    std::vector<DevMaterial> mats;
+    int rc = flatten_materials(s, mats, D.reflective);
+    if (rc) return rc;
+
+    // textures: one uchar4 pool and one ushort4 pool
+    std::vector<DevTexture> texs;
+    std::vector<uchar4> t8;
+    std::vector<ushort4> t16;
+    for (const HostTexture &t : s->textures) {
+        DevTexture d;
+        d.width = t.width;
+        d.height = t.height;
+        d.maxval = t.maxval;
+        size_t n = (size_t)t.width * t.height;
+        if (t.maxval <= 255) {
+            d.wide = 0;
+            d.offset = t8.size();
+            t8.resize(t8.size() + n);
+            for (size_t i = 0; i < n; i++) t8[d.offset + i] = make_uchar4(t.samples[i * 3], t.samples[i * 3 + 1], t.samples[i * 3 + 2], 255);
+        } else {
+            d.wide = 1;
+            d.offset = t16.size();
+            t16.resize(t16.size() + n);
+            for (size_t i = 0; i < n; i++) {
+                const uint8_t *p = &t.samples[i * 6];
+                t16[d.offset + i] = make_ushort4((uint16_t)((p[0] << 8) | p[1]), (uint16_t)((p[2] << 8) | p[3]), (uint16_t)((p[4] << 8) | p[5]), 0);
+            }
+        }
+        texs.push_back(d);
+    }
+    std::vector<DevLight> lights;
+    for (const rrt_light_desc &l : s->lights) {
+        DevLight d;
+        d.kind = l.kind;
+        d.position = mk3(l.position[0], l.position[1], l.position[2]);
+        d.direction = mk3(l.direction[0], l.direction[1], l.direction[2]);
+        d.intensity = mk3(l.colour[0], l.colour[1], l.colour[2]);
+        lights.push_back(d);
+    }
+
+#define UP(field, vec)                      \
+    if ((rc = D.field.upload(vec))) return rc;
+    UP(instrs, F.instrs)
+    UP(objects, F.objects)
+    UP(plane_hot, F.plane_hot)
+    UP(plane_cold, F.plane_cold)
+    UP(sphere_hot, F.sphere_hot)
+    UP(sphere_mat, F.sphere_mat)
+    UP(cuboid_hot, F.cuboid_hot)
+    UP(quadric_hot, F.quadric_hot)
+    UP(meshes, F.meshes)
+    UP(tris, F.tris)
+    UP(tri_index, F.tri_index)
+    UP(tri_normals, F.tri_normals)
+    UP(nodes, F.nodes)
+    UP(materials, mats)
+    UP(textures, texs)
+    UP(texels8, t8)
+    UP(texels16, t16)
+    UP(lights, lights)
+#undef UP
+    DevScene &V = D.view;
+    V.instrs = D.instrs.p;
+    V.objects = D.objects.p;
+    V.n_objects = (uint32_t)F.objects.size();
+    V.n_lights = (uint32_t)lights.size();
+    V.max_program = max_prog;
+    V.has_csg = has_csg ? 1 : 0;
+    V.plane_hot = D.plane_hot.p;
+    V.plane_cold = D.plane_cold.p;
+    V.sphere_hot = D.sphere_hot.p;
+    V.sphere_mat = D.sphere_mat.p;
+    V.cuboid_hot = D.cuboid_hot.p;
+    V.quadric_hot = D.quadric_hot.p;
+    V.meshes = D.meshes.p;
+    V.tris = D.tris.p;
+    V.tri_index = D.tri_index.p;
+    V.tri_normals = D.tri_normals.p;
+    V.nodes = D.nodes.p;
+    V.materials = D.materials.p;
+    V.textures = D.textures.p;
+    V.texels8 = D.texels8.p;
+    V.texels16 = D.texels16.p;
+    V.lights = D.lights.p;
+    s->flattened = true;
+    return ensure_workspace(s);
+}
+
+int ensure_workspace(rrt_scene *s) {
+    int rc;
+    if ((rc = s->counters.ensure(64))) return rc;
+    if ((rc = s->stats_dev.ensure(ST_COUNT))) return rc;
+    if (!s->host_pinned) RRT_HIP(hipHostMalloc((void **)&s->host_pinned, 64 * sizeof(uint32_t)));
+    while (s->events.size() < 4) {
+        hipEvent_t e;
+        RRT_HIP(hipEventCreate(&e));
+        s->events.push_back(e);
+    }
+    return RRT_OK;
+}
+
+// The render loop: one chunk of pixels at a time, one queue per recursion level.
+int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
+                const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream) {
+    if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
+    if (s->mode == RRT_MODE_PHOTON && !s->maps_built) return fail(RRT_ERR_STATE, "Photon map not built");
+    DeviceScene &D = s->dev;
+    const uint32_t n_lights = D.view.n_lights;
+    const uint32_t depth_cap = s->mode == RRT_MODE_SCENE ? s->params.max_depth : s->params.max_vueon_depth;
+    const uint32_t n_levels = D.reflective ? depth_cap + 1 : 1;
+    if (n_levels + 2 > 60) return fail(RRT_ERR_LIMIT, "recursion depth above 57");
+    if (s->levels.size() < n_levels + 1) s->levels.resize(n_levels + 1);
+    uint32_t chunk = s->params.chunk_pixels ? s->params.chunk_pixels : (1u << 20);
+    int rc;
+    uint32_t *err_dev = s->counters.p + 63;
+    RRT_HIP(hipMemsetAsync(s->counters.p, 0, 64 * sizeof(uint32_t), stream));
+    RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, ST_COUNT * sizeof(unsigned long long), stream));
+    RRT_HIP(hipEventRecord(s->events[0], stream));
+    uint64_t secondary = 0;
+    float ms_trace = 0.0f;
+    for (uint32_t base = 0; base < n_pixels; base += chunk) {
+        uint32_t n = std::min(chunk, n_pixels - base);
+        std::vector<uint32_t> counts(n_levels + 1, 0);
+        counts[0] = n;
+        if ((rc = s->levels[0].ensure(n, n_lights, cam == nullptr))) return rc;
+        if (!cam) launch_load_rays(origins_dev + (size_t)base * 3, directions_dev + (size_t)base * 3, n, s->levels[0].view(), stream);
+        TraceArgs A;
+        memset(&A, 0, sizeof(A));
+        A.S = D.view;
+        if (cam) A.cam = *cam;
+        A.maps[0] = s->index[0].view();
+        A.maps[1] = s->index[1].view();
+        A.max_depth = depth_cap;
+        A.mode = (uint32_t)s->mode;
+        A.y0 = y0;
+        A.pixel_base = base;
+        A.lds_slots = D.lds_slots;
+        A.gather_half_width = s->params.gather_half_width;
+        A.err = err_dev;
+        A.stats = s->stats_dev.p;
+        A.out_rgb = rgb_dev;
+        A.out_depth = depth_dev;
+        A.out_id = id_dev;
+        uint32_t last = 0;
+        RRT_HIP(hipMemsetAsync(s->counters.p, 0, 60 * sizeof(uint32_t), stream));
+        for (uint32_t k = 0; k < n_levels; k++) {
+            bool spawns = k + 1 < n_levels;
+            if (spawns && (rc = s->levels[k + 1].ensure(2 * counts[k], n_lights, true))) return rc;
+            A.cur = s->levels[k].view();
+            A.next = s->levels[k + 1].view();
+            A.count = counts[k];
+            A.level = k;
+            A.next_count = s->counters.p + (k + 1);
+            RRT_HIP(hipEventRecord(s->events[2], stream));
+            launch_trace_shade(A, D.lds_bytes, stream);
+            RRT_HIP(hipEventRecord(s->events[3], stream));
+            last = k;
+            uint32_t next_n = 0;
+            if (spawns) {
+                RRT_HIP(hipMemcpyAsync(s->host_pinned, s->counters.p + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                RRT_HIP(hipStreamSynchronize(stream));
+                next_n = s->host_pinned[0];
+            } else {
+                RRT_HIP(hipStreamSynchronize(stream));
+            }
+            float ms = 0.0f;
+            RRT_HIP(hipEventElapsedTime(&ms, s->events[2], s->events[3]));
+            ms_trace += ms;
+            counts[k + 1] = next_n;
+            secondary += next_n;
+            if (next_n == 0) break;
+        }
+        for (int k = (int)last; k >= 0; k--) {
+            A.cur = s->levels[k].view();
+            A.next = s->levels[k + 1].view();
+            A.count = counts[k];
+            A.level = (uint32_t)k;
+            launch_combine(A, stream);
+        }
+    }
+    RRT_HIP(hipEventRecord(s->events[1], stream));
+    RRT_HIP(hipMemcpyAsync(s->host_pinned, err_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    unsigned long long st[ST_COUNT];
+    RRT_HIP(hipMemcpyAsync(st, s->stats_dev.p, sizeof(st), hipMemcpyDeviceToHost, stream));
+    RRT_HIP(hipStreamSynchronize(stream));
+    float ms_total = 0.0f;
+    RRT_HIP(hipEventElapsedTime(&ms_total, s->events[0], s->events[1]));
+    rrt_stats &R = s->stats;
+    R.rays_primary = n_pixels;
+    R.rays_secondary = secondary;
+    R.rays_shadow = st[ST_SHADOW];
+    R.bvh_nodes_visited = st[ST_NODES];
+    R.bvh_tris_tested = st[ST_TRIS];
+    R.photons_gathered = st[ST_GATHERED];
+    R.gather_queries = st[ST_QUERIES];
+    R.gather_candidates = st[ST_CANDIDATES];
+    R.ms_trace_kernels = ms_trace;
+    R.ms_total = ms_total;
+    uint32_t err = s->host_pinned[0];
+    if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
+    if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
+    return RRT_OK;
+}
+
+}  // namespace rrt
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+namespace {
+
+int b_set_mode(void *ctx, int mode) { return rrt_scene_set_mode((rrt_scene *)ctx, mode); }
+int b_add_texture(void *ctx, uint32_t w, uint32_t h, uint32_t mv, const uint8_t *p) { return rrt_add_texture((rrt_scene *)ctx, w, h, mv, p); }
+int b_add_material(void *ctx, const rrt_material_desc *d) { return rrt_add_material((rrt_scene *)ctx, d); }
+int b_object_define(void *ctx, const rrt_object_desc *d) { return rrt_object_define((rrt_scene *)ctx, d); }
+int b_object_transform(void *ctx, int h, const float *m) { return rrt_object_transform((rrt_scene *)ctx, h, m); }
+int b_add_object(void *ctx, int h) { return rrt_add_object((rrt_scene *)ctx, h); }
+int b_add_light(void *ctx, const rrt_light_desc *d) { return rrt_add_light((rrt_scene *)ctx, d); }
+
+DevCamera to_dev(const rrt_camera *c) {
+    DevCamera d;
+    d.position = mk3(c->position[0], c->position[1], c->position[2]);
+    d.right = mk3(c->right[0], c->right[1], c->right[2]);
+    d.up = mk3(c->up[0], c->up[1], c->up[2]);
+    d.lookat = mk3(c->lookat[0], c->lookat[1], c->lookat[2]);
+    d.fov = c->fov;
+    d.width = c->width;
+    d.height = c->height;
+    return d;
+}
+
+void invalidate(rrt_scene *s) {
+    s->flattened = false;
+    s->maps_built = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rrt_last_error(void) { return rrt::last_error_cstr(); }
+const char *rrt_version(void) { return "rrt 0.1 (gfx950)"; }
+
+void rrt_params_default(rrt_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->photons_per_light = 5000000;
+    p->caustic_photons_per_light = 10000;
+    p->gather_half_width = 0.1f;
+    p->max_depth = 5;
+    p->max_photon_bounces = 64;
+    p->max_vueon_depth = 12;
+    p->chunk_pixels = 0;
+}
+
+rrt_scene *rrt_scene_create(int mode, const rrt_params *params) {
+    if (mode != RRT_MODE_SCENE && mode != RRT_MODE_PHOTON) {
+        set_error("bad mode");
+        return nullptr;
+    }
+    rrt_scene *s = new rrt_scene();
+    s->mode = mode;
+    if (params)
+        s->params = *params;
+    else
+        rrt_params_default(&s->params);
+    s->builder = rrt_builder{s, b_set_mode, b_add_texture, b_add_material, b_object_define, b_object_transform, b_add_object, b_add_light};
+    return s;
+}
+void rrt_scene_destroy(rrt_scene *s) { delete s; }
+int rrt_scene_set_mode(rrt_scene *s, int mode) {
+    if (!s || (mode != RRT_MODE_SCENE && mode != RRT_MODE_PHOTON)) return fail(RRT_ERR_INVALID, "bad mode");
+    s->mode = mode;
+    return RRT_OK;
+}
+int rrt_scene_get_mode(const rrt_scene *s) { return s ? s->mode : RRT_ERR_INVALID; }
+int rrt_scene_set_params(rrt_scene *s, const rrt_params *params) {
+    if (!s || !params) return fail(RRT_ERR_INVALID, "null argument");
+    if (params->max_depth > 40 || params->max_vueon_depth > 40 || params->max_photon_bounces > 64)
+        return fail(RRT_ERR_LIMIT, "max_depth/max_vueon_depth <= 40, max_photon_bounces <= 64");
+    s->params = *params;
+    s->maps_built = false;
+    return RRT_OK;
+}
+const rrt_builder *rrt_scene_builder(rrt_scene *s) { return s ? &s->builder : nullptr; }
+int rrt_object_count(const rrt_scene *s) { return s ? (int)s->objects.size() : RRT_ERR_INVALID; }
+int rrt_light_count(const rrt_scene *s) { return s ? (int)s->lights.size() : RRT_ERR_INVALID; }
+
+int rrt_add_texture(rrt_scene *s, uint32_t width, uint32_t height, uint32_t maxval, const uint8_t *samples) {
+    if (!s || !samples || width == 0 || height == 0 || maxval == 0 || maxval > 65535) return fail(RRT_ERR_INVALID, "bad texture");
+    HostTexture t;
+    t.width = width;
+    t.height = height;
+    t.maxval = maxval;
+    size_t bytes = (size_t)width * height * 3 * (maxval <= 255 ? 1 : 2);
+    t.samples.assign(samples, samples + bytes);
+    s->textures.push_back(std::move(t));
+    invalidate(s);
+    return (int)s->textures.size() - 1;
+}
+int rrt_add_texture_ppm(rrt_scene *s, const char *path) {
+    if (!s || !path) return fail(RRT_ERR_INVALID, "null argument");
+    HostTexture t;
+    int rc = read_ppm(path, t);
+    if (rc) return rc;
+    s->textures.push_back(std::move(t));
+    invalidate(s);
+    return (int)s->textures.size() - 1;
+}
+
+int rrt_add_material(rrt_scene *s, const rrt_material_desc *d) {
+    if (!s || !d) return fail(RRT_ERR_INVALID, "null argument");
+    int nt = (int)s->textures.size();
+    switch (d->kind) {
+        case RRT_MAT_MONOCHROME:
+        case RRT_MAT_GLOBAL:
+        case RRT_MAT_FALSECOLOUR: break;
+        case RRT_MAT_TEXTURE:
+            if (d->diffuse_tex < 0 || d->diffuse_tex >= nt || d->normal_tex >= nt) return fail(RRT_ERR_INVALID, "bad texture id");
+            break;
+        case RRT_MAT_COMPOUND:
+            if (d->n_parts < 1 || d->n_parts > RRT_MAX_COMPOUND_PARTS) return fail(RRT_ERR_LIMIT, "compound needs 1..4 parts");
+            for (int i = 0; i < d->n_parts; i++) {
+                if (d->parts[i] < 0 || d->parts[i] >= (int)s->materials.size()) return fail(RRT_ERR_INVALID, "bad compound part id");
+                int k = s->materials[d->parts[i]].kind;
+                if (k == RRT_MAT_COMPOUND) return fail(RRT_ERR_LIMIT, "compound parts may not be compounds");
+                if (k == RRT_MAT_GLOBAL && i != d->n_parts - 1) return fail(RRT_ERR_LIMIT, "a Global part must be the last part of a compound");
+            }
+            break;
+        default: return fail(RRT_ERR_INVALID, "bad material kind");
+    }
+    s->materials.push_back(*d);
+    invalidate(s);
+    return (int)s->materials.size() - 1;
+}
+
+int rrt_object_define(rrt_scene *s, const rrt_object_desc *d) {
+    if (!s || !d) return fail(RRT_ERR_INVALID, "null argument");
+    auto o = std::make_unique<HostObject>();
+    o->kind = d->kind;
+    o->material = d->material;
+    if (d->kind != RRT_OBJ_CSG && (d->material < 0 || d->material >= (int)s->materials.size())) return fail(RRT_ERR_INVALID, "bad material id");
+    const float *v = d->v;
+    switch (d->kind) {
+        case RRT_OBJ_PLANE:
+            o->p0 = mk3(v[0], v[1], v[2]);
+            o->p1 = mk3(v[3], v[4], v[5]);
+            o->p2 = mk3(v[6], v[7], v[8]);
+            o->d = -dot3(o->p2, o->p0);  // plane_object.rs:37
+            break;
+        case RRT_OBJ_SPHERE:
+            o->p0 = mk3(v[0], v[1], v[2]);
+            o->radius = v[3];
+            break;
+        case RRT_OBJ_CUBOID:
+            o->p0 = mk3(v[0], v[1], v[2]);
+            o->p1 = mk3(v[3], v[4], v[5]);
+            break;
+        case RRT_OBJ_QUADRATIC:
+            for (int i = 0; i < 10; i++) o->q[i] = v[i];
+            break;
+        case RRT_OBJ_MESH:
+            if (!d->positions && d->n_triangles) return fail(RRT_ERR_INVALID, "mesh without positions");
+            if (d->smooth && !d->normals) return fail(RRT_ERR_INVALID, "Vertex normals not set in smoothen_hit()");
+            if (d->n_triangles >= (1u << 27)) return fail(RRT_ERR_LIMIT, "mesh larger than 2^27 triangles");
+            o->tri_pos.assign(d->positions, d->positions + d->n_triangles * 9);
+            if (d->normals) o->tri_nrm.assign(d->normals, d->normals + d->n_triangles * 9);
+            o->smooth = d->smooth != 0;
+            break;
+        case RRT_OBJ_CSG: {
+            int n = (int)s->detached.size();
+            if (d->csg_mode < 0 || d->csg_mode > 2) return fail(RRT_ERR_INVALID, "bad csg mode");
+            if (d->left < 0 || d->left >= n || d->right < 0 || d->right >= n || d->left == d->right || !s->detached[d->left] ||
+                !s->detached[d->right])
+                return fail(RRT_ERR_INVALID, "bad csg child handle");
+            if (s->detached[d->left]->contains_mesh() || s->detached[d->right]->contains_mesh())
+                return fail(RRT_ERR_LIMIT, "meshes cannot be CSG children in this build");
+            o->csg_mode = d->csg_mode;
+            o->left = std::move(s->detached[d->left]);
+            o->right = std::move(s->detached[d->right]);
+            break;
+        }
+        default: return fail(RRT_ERR_INVALID, "bad object kind");
+    }
+    s->detached.push_back(std::move(o));
+    return (int)s->detached.size() - 1;
+}
+
+int rrt_object_define_obj(rrt_scene *s, const char *obj_path, int material, int smooth) {
+    if (!s || !obj_path) return fail(RRT_ERR_INVALID, "null argument");
+    std::vector<float> pos, nrm;
+    int rc = load_obj(obj_path, smooth != 0, pos, nrm);
+    if (rc) return rc;
+    rrt_object_desc d;
+    memset(&d, 0, sizeof(d));
+    d.kind = RRT_OBJ_MESH;
+    d.material = material;
+    d.positions = pos.data();
+    d.normals = nrm.empty() ? nullptr : nrm.data();
+    d.n_triangles = pos.size() / 9;
+    d.smooth = smooth;
+    return rrt_object_define(s, &d);
+}
+
+int rrt_object_transform(rrt_scene *s, int handle, const float *m16) {
+    if (!s || !m16 || handle < 0 || handle >= (int)s->detached.size() || !s->detached[handle]) return fail(RRT_ERR_INVALID, "bad handle");
+    float m[4][4];
+    memcpy(m, m16, sizeof(m));
+    try {
+        s->detached[handle]->apply_transform(m);
+    } catch (int) {
+        return RRT_ERR_INVALID;  // message set by the thrower ("Matrix is not invertible")
+    }
+    return RRT_OK;
+}
+
+int rrt_add_object(rrt_scene *s, int handle) {
+    if (!s || handle < 0 || handle >= (int)s->detached.size() || !s->detached[handle]) return fail(RRT_ERR_INVALID, "bad handle");
+    s->objects.push_back(std::move(s->detached[handle]));
+    invalidate(s);
+    return (int)s->objects.size() - 1;
+}
+
+int rrt_add_light(rrt_scene *s, const rrt_light_desc *d) {
+    if (!s || !d || d->kind < 0 || d->kind > 2) return fail(RRT_ERR_INVALID, "bad light");
+    s->lights.push_back(*d);
+    invalidate(s);
+    return (int)s->lights.size() - 1;
+}
+
+// full_camera.rs:23-58
+int rrt_camera_init(rrt_camera *cam, uint32_t width, uint32_t height, float fov, const float position[3], const float lookat_in[3],
+                    const float up_in[3]) {
+    if (!cam || !position || !lookat_in || !up_in) return fail(RRT_ERR_INVALID, "null argument");
+    if (width == 0 || height == 0) return fail(RRT_ERR_INVALID, "Invalid framebuffer size");
+    f3 lookat = mk3(lookat_in[0], -lookat_in[1], lookat_in[2]);
+    f3 up = mk3(up_in[0], -up_in[1], up_in[2]);
+    lookat = norm3(lookat);
+    up = norm3(up);
+    float dotp = dot3(lookat, up);
+    float len = len3(lookat) * len3(up);
+    float ang = acosf(dotp) / len;  // vector.rs:114-119
+    const float right_angle = 1.57079632679489661923f;
+    if (fabsf(ang - right_angle) > 0.0001f) return fail(RRT_ERR_INVALID, "FullCamera right and up are not perpendicular");
+    f3 right = norm3(cross3(lookat, up));
+    cam->width = width;
+    cam->height = height;
+    cam->fov = fov;
+    for (int i = 0; i < 3; i++) cam->position[i] = position[i];
+    cam->lookat[0] = lookat.x; cam->lookat[1] = lookat.y; cam->lookat[2] = lookat.z;
+    cam->up[0] = up.x; cam->up[1] = up.y; cam->up[2] = up.z;
+    cam->right[0] = right.x; cam->right[1] = right.y; cam->right[2] = right.z;
+    return RRT_OK;
+}
+
+// full_camera.rs:61-81
+int rrt_camera_ray(const rrt_camera *cam, uint32_t x, uint32_t y, float origin[3], float direction[3]) {
+    if (!cam || x >= cam->width || y >= cam->height) return fail(RRT_ERR_INVALID, "pixel out of range");
+    float fx = ((float)x + 0.5f) / (float)cam->width;
+    float fy = ((float)y + 0.5f) / (float)cam->height;
+    f3 v = mk3(fx - 0.5f, fy - 0.5f, cam->fov);
+    f3 d = norm3(mk3(cam->right[0] * v.x + cam->up[0] * v.y + cam->lookat[0] * v.z, cam->right[1] * v.x + cam->up[1] * v.y + cam->lookat[1] * v.z,
+                     cam->right[2] * v.x + cam->up[2] * v.y + cam->lookat[2] * v.z));
+    for (int i = 0; i < 3; i++) origin[i] = cam->position[i];
+    direction[0] = d.x; direction[1] = d.y; direction[2] = d.z;
+    return RRT_OK;
+}
+
+rrt_scene *rrt_scene_load(const char *path, const char *asset_root, const rrt_params *params, int mode_override, rrt_camera *camera_out) {
+    rrt_scene *s = rrt_scene_create(RRT_MODE_SCENE, params);
+    if (!s) return nullptr;
+    uint32_t line = 0;
+    int rc = rrt_parse_scene_file(path, asset_root, &s->builder, camera_out, mode_override, &line);
+    if (rc) {
+        rrt_scene_destroy(s);
+        return nullptr;
+    }
+    return s;
+}
+
+int rrt_pre_render(rrt_scene *s, uint64_t seed) {
+    if (!s) return fail(RRT_ERR_INVALID, "null scene");
+    if (s->mode == RRT_MODE_PHOTON) {
+        int rc = rrt_photon_begin(s, seed);
+        if (rc) return rc;
+        for (int l = 0; l < (int)s->lights.size(); l++) {
+            if ((rc = rrt_photon_shoot(s, l, 0, 0, s->params.photons_per_light))) return rc;
+            if ((rc = rrt_photon_shoot(s, l, 1, 0, s->params.caustic_photons_per_light))) return rc;
+        }
+        return rrt_photon_build(s);
+    }
+    s->seed = seed;
+    return flatten_scene(s);
+}
+
+int rrt_render_device(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t y1, float *rgb_dev, float *depth_dev,
+                      uint32_t *object_id_dev, void *hip_stream) {
+    if (!s || !cam) return fail(RRT_ERR_INVALID, "null argument");
+    if (y0 > y1 || y1 > cam->height) return fail(RRT_ERR_INVALID, "bad row range");
+    uint64_t n = (uint64_t)(y1 - y0) * cam->width;
+    if (n >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 pixels in one band");
+    DevCamera dc = to_dev(cam);
+    return render_rays(s, &dc, y0, (uint32_t)n, nullptr, nullptr, rgb_dev, depth_dev, object_id_dev, (hipStream_t)hip_stream);
+}
+
+int rrt_render(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t y1, float *rgb, float *depth, uint32_t *object_id) {
+    if (!s || !cam) return fail(RRT_ERR_INVALID, "null argument");
+    if (y0 > y1 || y1 > cam->height) return fail(RRT_ERR_INVALID, "bad row range");
+    if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
+    size_t n = (size_t)(y1 - y0) * cam->width;
+    DBuf<float> d_rgb, d_depth;
+    DBuf<uint32_t> d_id;
+    int rc;
+    if ((rc = d_rgb.ensure(n * 3))) return rc;
+    if ((rc = d_depth.ensure(n))) return rc;
+    if ((rc = d_id.ensure(n))) return rc;
+    rc = rrt_render_device(s, cam, y0, y1, d_rgb.p, d_depth.p, d_id.p, nullptr);
+    if (rc) return rc;
+    if (rgb) RRT_HIP(hipMemcpy(rgb, d_rgb.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (depth) RRT_HIP(hipMemcpy(depth, d_depth.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (object_id) RRT_HIP(hipMemcpy(object_id, d_id.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RRT_OK;
+}
+
+int rrt_raytrace(rrt_scene *s, const float *origins, const float *directions, size_t n, float *rgb, float *depth, uint32_t *object_id) {
+    if (!s || !origins || !directions) return fail(RRT_ERR_INVALID, "null argument");
+    if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
+    if (n >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 rays");
+    DBuf<float> d_o, d_d, d_rgb, d_depth;
+    DBuf<uint32_t> d_id;
+    int rc;
+    if ((rc = d_o.ensure(n * 3)) || (rc = d_d.ensure(n * 3)) || (rc = d_rgb.ensure(n * 3)) || (rc = d_depth.ensure(n)) || (rc = d_id.ensure(n)))
+        return rc;
+    RRT_HIP(hipMemcpy(d_o.p, origins, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    RRT_HIP(hipMemcpy(d_d.p, directions, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    rc = render_rays(s, nullptr, 0, (uint32_t)n, d_o.p, d_d.p, d_rgb.p, d_depth.p, d_id.p, nullptr);
+    if (rc) return rc;
+    if (rgb) RRT_HIP(hipMemcpy(rgb, d_rgb.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (depth) RRT_HIP(hipMemcpy(depth, d_depth.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (object_id) RRT_HIP(hipMemcpy(object_id, d_id.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RRT_OK;
+}
+
+static int batch_common(rrt_scene *s, const float *origins, const float *directions, const float *limits, size_t n, uint32_t *object_id,
+                        uint32_t *prim_id, float *distance, float *position, float *normal, float *uv, uint8_t *occluded, bool shadow) {
+    if (!s || !origins || !directions) return fail(RRT_ERR_INVALID, "null argument");
+    if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
+    if (n >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 rays");
+    DBuf<float> d_o, d_d, d_lim, d_dist, d_pos, d_nrm, d_uv;
+    DBuf<uint32_t> d_id, d_prim;
+    DBuf<uint8_t> d_occ;
+    int rc;
+    if ((rc = d_o.ensure(n * 3)) || (rc = d_d.ensure(n * 3))) return rc;
+    RRT_HIP(hipMemcpy(d_o.p, origins, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    RRT_HIP(hipMemcpy(d_d.p, directions, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    BatchTraceArgs A;
+    memset(&A, 0, sizeof(A));
+    A.S = s->dev.view;
+    A.origins = d_o.p;
+    A.directions = d_d.p;
+    A.n = (uint32_t)n;
+    A.lds_slots = s->dev.lds_slots;
+    A.err = s->counters.p + 63;
+    A.stats = s->stats_dev.p;
+    RRT_HIP(hipMemset(s->counters.p, 0, 64 * sizeof(uint32_t)));
+    RRT_HIP(hipMemset(s->stats_dev.p, 0, ST_COUNT * sizeof(unsigned long long)));
+    if (shadow) {
+        if (!limits || !occluded) return fail(RRT_ERR_INVALID, "null argument");
+        if ((rc = d_lim.ensure(n)) || (rc = d_occ.ensure(n))) return rc;
+        RRT_HIP(hipMemcpy(d_lim.p, limits, n * sizeof(float), hipMemcpyHostToDevice));
+        A.limits = d_lim.p;
+        A.occluded = d_occ.p;
+        launch_batch_shadow(A, s->dev.lds_bytes, nullptr);
+    } else {
+        if ((rc = d_id.ensure(n)) || (rc = d_prim.ensure(n)) || (rc = d_dist.ensure(n)) || (rc = d_pos.ensure(n * 3)) || (rc = d_nrm.ensure(n * 3)) ||
+            (rc = d_uv.ensure(n * 2)))
+            return rc;
+        A.object_id = d_id.p;
+        A.prim_id = d_prim.p;
+        A.distance = d_dist.p;
+        A.position = d_pos.p;
+        A.normal = d_nrm.p;
+        A.uv = d_uv.p;
+        launch_batch_trace(A, s->dev.lds_bytes, nullptr);
+    }
+    RRT_HIP(hipGetLastError());
+    RRT_HIP(hipDeviceSynchronize());
+    uint32_t err = 0;
+    RRT_HIP(hipMemcpy(&err, s->counters.p + 63, sizeof(err), hipMemcpyDeviceToHost));
+    unsigned long long st[ST_COUNT];
+    RRT_HIP(hipMemcpy(st, s->stats_dev.p, sizeof(st), hipMemcpyDeviceToHost));
+    s->stats.bvh_nodes_visited = st[ST_NODES];
+    s->stats.bvh_tris_tested = st[ST_TRIS];
+    if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
+    if (shadow) {
+        RRT_HIP(hipMemcpy(occluded, d_occ.p, n, hipMemcpyDeviceToHost));
+    } else {
+        if (object_id) RRT_HIP(hipMemcpy(object_id, d_id.p, n * 4, hipMemcpyDeviceToHost));
+        if (prim_id) RRT_HIP(hipMemcpy(prim_id, d_prim.p, n * 4, hipMemcpyDeviceToHost));
+        if (distance) RRT_HIP(hipMemcpy(distance, d_dist.p, n * 4, hipMemcpyDeviceToHost));
+        if (position) RRT_HIP(hipMemcpy(position, d_pos.p, n * 12, hipMemcpyDeviceToHost));
+        if (normal) RRT_HIP(hipMemcpy(normal, d_nrm.p, n * 12, hipMemcpyDeviceToHost));
+        if (uv) RRT_HIP(hipMemcpy(uv, d_uv.p, n * 8, hipMemcpyDeviceToHost));
+    }
+    return RRT_OK;
+}
+
+int rrt_trace(rrt_scene *s, const float *origins, const float *directions, size_t n, uint32_t *object_id, uint32_t *prim_id, float *distance,
+              float *position, float *normal, float *uv) {
+    return batch_common(s, origins, directions, nullptr, n, object_id, prim_id, distance, position, normal, uv, nullptr, false);
+}
+int rrt_shadowtrace(rrt_scene *s, const float *origins, const float *directions, const float *limits, size_t n, uint8_t *occluded) {
+    return batch_common(s, origins, directions, limits, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, occluded, true);
+}
+
+int rrt_get_stats(const rrt_scene *s, rrt_stats *out) {
+    if (!s || !out) return fail(RRT_ERR_INVALID, "null argument");
+    *out = s->stats;
+    return RRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// runtime.h — host runtime of librrt: the scene handle, device storage and queue workspace.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "host_scene.h"
+#include "kernels.h"
+
+namespace rrt {
+
+const char *last_error_cstr();
+
+#define RRT_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return ::rrt::fail(RRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+// grow-only device array
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    ~DBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    int ensure(size_t n) {
+        if (n <= cap) return RRT_OK;
+        release();
+        if (n == 0) return RRT_OK;
+        RRT_HIP(hipMalloc((void **)&p, n * sizeof(T)));
+        cap = n;
+        return RRT_OK;
+    }
+    int upload(const std::vector<T> &v) {
+        int rc = ensure(v.size() ? v.size() : 1);
+        if (rc) return rc;
+        if (!v.empty()) RRT_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return RRT_OK;
+    }
+};
+
+struct LevelStorage {
+    DBuf<float4> ray_o, ray_d, once, glob, lights, result;
+    DBuf<int2> child;
+    DBuf<uint32_t> object_id;
+    uint32_t capacity = 0;
+    int ensure(uint32_t n, uint32_t n_lights, bool need_rays);
+    LevelBuffers view() const;
+};
+
+struct DeviceScene {
+    DBuf<Instr> instrs;
+    DBuf<ObjectRange> objects;
+    DBuf<float4> plane_hot;
+    DBuf<PlaneCold> plane_cold;
+    DBuf<float4> sphere_hot;
+    DBuf<int32_t> sphere_mat;
+    DBuf<CuboidHot> cuboid_hot;
+    DBuf<QuadricHot> quadric_hot;
+    DBuf<MeshInfo> meshes;
+    DBuf<TriHot> tris;
+    DBuf<uint32_t> tri_index;
+    DBuf<float> tri_normals;
+    DBuf<BvhNode> nodes;
+    DBuf<DevMaterial> materials;
+    DBuf<DevTexture> textures;
+    DBuf<uchar4> texels8;
+    DBuf<ushort4> texels16;
+    DBuf<DevLight> lights;
+    DevScene view{};
+    uint32_t lds_slots = 0;
+    uint32_t bvh_stack = 0;
+    size_t lds_bytes = 0;
+    bool reflective = false;
+    uint64_t flops_per_trace = 0;  // analytic primitives only
+};
+
+// photon buffers in HBM (photon.hip)
+struct PhotonBuffers {
+    DBuf<float4> pos, dir, rgb;  // pos.w = photon type as uint bits
+    DBuf<uint64_t> meta;         // (light*2+pass) << 56 | key
+    uint64_t count = 0;
+};
+struct PhotonIndex {
+    DBuf<float4> pos, dir, rgb;
+    DBuf<uint64_t> keys;
+    DBuf<uint2> ranges;
+    uint32_t table_size = 0;
+    uint64_t count = 0;
+    float inv_cell = 0.0f;
+    DevPhotonMap view() const;
+};
+struct CausticSeeds {
+    DBuf<float4> pos, dir;
+    DBuf<uint64_t> key;
+    uint64_t count = 0;
+};
+
+}  // namespace rrt
+
+struct rrt_scene {
+    int mode = RRT_MODE_SCENE;
+    rrt_params params{};
+    std::vector<rrt::HostTexture> textures;
+    std::vector<rrt_material_desc> materials;
+    std::vector<std::unique_ptr<rrt::HostObject>> detached;
+    std::vector<std::unique_ptr<rrt::HostObject>> objects;
+    std::vector<rrt_light_desc> lights;
+    rrt_builder builder{};
+
+    bool flattened = false;
+    bool maps_built = false;
+    uint64_t seed = 0;
+    rrt::DeviceScene dev;
+    std::vector<rrt::LevelStorage> levels;
+    rrt::DBuf<uint32_t> counters;             // per-level queue lengths + error word
+    rrt::DBuf<unsigned long long> stats_dev;  // StatSlot counters
+    uint32_t *host_pinned = nullptr;          // readback staging
+    rrt_stats stats{};
+    std::vector<hipEvent_t> events;
+
+    // photon state
+    rrt::PhotonBuffers local[2];  // this rank's records: regular, caustic
+    std::vector<std::unique_ptr<rrt::CausticSeeds>> seeds;  // per light
+    rrt::PhotonIndex index[2];
+
+    ~rrt_scene();
+};
+
+namespace rrt {
+int flatten_scene(rrt_scene *s);
+int ensure_workspace(rrt_scene *s);
+int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
+                const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream);
+void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth);
+int read_ppm(const std::string &path, HostTexture &tex);
+int load_obj(const std::string &path, bool smooth, std::vector<float> &tri_pos, std::vector<float> &tri_nrm);
+}  // namespace rrt
