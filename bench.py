@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the render hot path on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1]): the quadric + CSG + Fresnel scene
+`assets/scenes/c2_quadric_csg_fresnel.txt` at 1920x1080.  One "step" = one full frame through
+the wavefront pipeline (primary rays, up to 5 levels of reflection/refraction rays, shadow rays),
+scene resident in HBM, outputs written to HBM.  Metric: Mrays/s = (primary + secondary + shadow
+rays traced) / wall time.  With N ranks every rank renders its own frame of a camera orbit per step
+(frames are independent objects: no data-path collective), so scaling is "weak".
+
+Extra legs (same JSON line): `cpu_baseline` = the CPU oracle (a port of the reference's brute-force
+algorithm; the Rust binary cannot be built here) on a bounded sample of rows of the same frame;
+`roofline` = k_trace_shade against the MI355X vector-FP32 peak, timed with HIP events on the launch
+stream inside librrt (rrt_stats.ms_trace_kernels); `mesh` and `photon` = the other two single-GPU
+configs of BASELINE.json, short runs.
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def orbit_camera(rrt, base, rank, step):
+    """Frame `step` of rank `rank`: the C2 camera moved along x (keeps lookat/up perpendicular)."""
+    import ctypes as C
+
+    cam = type(base)()
+    C.memmove(C.byref(cam), C.byref(base), C.sizeof(base))
+    if rank or step:
+        cam.position[0] = base.position[0] + 0.15 * rank + 0.01 * (step % 8)
+    return cam
+
+
+def cpu_baseline(scene_path, cam, stride=12):
+    """Oracle (CPU port of the reference algorithm) on every `stride`-th row of the same frame."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_binding as ob
+
+    so, _ = ob.OracleScene.load(scene_path)
+    cores = min(16, os.cpu_count() or 1)
+    rows = list(range(0, cam.height, stride))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as pool:
+        list(pool.map(lambda y: so.render(cam, y, y + 1, threads=1), rows))
+    dt = time.perf_counter() - t0
+    st = so.stats()
+    rays = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+    return {
+        "value": rays / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "every %dth row of the same 1920x1080 frame (%d rows, %d rays, %.1f s)" % (stride, len(rows), rays, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--scene", default=os.path.join(REPO, "assets/scenes/c2_quadric_csg_fresnel.txt"))
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: librrt has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rrt = importlib.import_module("rust-raytracer_amd")
+    scene, cam0 = rrt.Scene.load(args.scene)
+    scene.pre_render(seed=1)
+    W, H = cam0.width, cam0.height
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        cam = orbit_camera(rrt, cam0, rank, i)
+        scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), stream)
+        return scene.stats()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    rays = 0
+    kernel_ms = 0.0
+    flops = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        st = step(i)
+        rays += st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+        kernel_ms += st["ms_trace_kernels"]
+        flops += st["flops_algorithmic"]
+    sync()
+    dt = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        r = torch.tensor([rays], dtype=torch.float64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        total_rays = float(r.item())
+    else:
+        total_rays = float(rays)
+
+    if rank == 0:
+        achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (primary+secondary+shadow rays traced)",
+            "value": total_rays / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: quadric + CSG + Fresnel scene, 1920x1080, one frame per rank per step",
+                "scene": os.path.relpath(args.scene, REPO),
+                "rays_per_frame": rays // max(1, args.steps),
+                "parallelism": "frames sharded over %d rank(s), no collective" % world,
+            },
+            "roofline": {
+                "kernel": "k_trace_shade (all recursion levels of a frame)",
+                "bound": "valu_fp32",
+                "achieved": achieved,
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS,
+                "traffic": None,
+                "kernel_ms_per_frame": kernel_ms / max(1, args.steps),
+                "algorithmic_flops_per_frame": flops // max(1, args.steps),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.scene, cam0)
+        if world == 1 and not args.no_extra:
+            try:
+                import bench_extra
+
+                out["extra"] = bench_extra.run(rrt, torch)
+            except Exception as e:  # extra legs must never hide the headline number
+                out["extra"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,7 +149,9 @@ typedef struct rrt_stats {
     double ms_total;             /* HIP-event time of the whole call on its stream          */
     double ms_photon_shoot;
     double ms_photon_build;
-    uint64_t reserved[8];
+    uint64_t flops_algorithmic;  /* SURVEY.md 8d count: per-primitive flops x tests + 27/box + 61/triangle */
+    uint64_t flops_per_trace;    /* analytic-primitive flops one trace() of this scene costs           */
+    uint64_t reserved[6];
 } rrt_stats;
 
 /* ---- builder vtable --------------------------------------------------------------------

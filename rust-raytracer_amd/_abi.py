@@ -94,7 +94,9 @@ class Stats(C.Structure):
         ("ms_total", C.c_double),
         ("ms_photon_shoot", C.c_double),
         ("ms_photon_build", C.c_double),
-        ("reserved", C.c_uint64 * 8),
+        ("flops_algorithmic", C.c_uint64),
+        ("flops_per_trace", C.c_uint64),
+        ("reserved", C.c_uint64 * 6),
     ]
 
     def as_dict(self):

@@ -479,6 +479,8 @@ int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixe
     R.photons_gathered = st[ST_GATHERED];
     R.gather_queries = st[ST_QUERIES];
     R.gather_candidates = st[ST_CANDIDATES];
+    R.flops_per_trace = D.flops_per_trace;
+    R.flops_algorithmic = (R.rays_primary + R.rays_secondary + R.rays_shadow) * D.flops_per_trace + 27ull * st[ST_NODES] + 61ull * st[ST_TRIS];
     R.ms_trace_kernels = ms_trace;
     R.ms_total = ms_total;
     uint32_t err = s->host_pinned[0];
