@@ -87,6 +87,14 @@ _sig("rrt_shadowtrace", C.c_int, C.c_void_p, _f32p, _f32p, _f32p, C.c_size_t, _u
 _sig("rrt_photon_begin", C.c_int, C.c_void_p, C.c_uint64)
 _sig("rrt_photon_shoot", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64)
 _sig("rrt_photon_build", C.c_int, C.c_void_p)
+_sig("rrt_photon_count", C.c_int, C.c_void_p, C.c_int, _u64p)
+_sig("rrt_photon_read", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _f32p, _u8p, _u64p)
+_sig("rrt_photon_caustic_count", C.c_int, C.c_void_p, C.c_int, _u64p)
+_sig("rrt_photon_caustic_export_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("rrt_photon_caustic_import_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+_sig("rrt_photon_local_count", C.c_int, C.c_void_p, C.c_int, _u64p)
+_sig("rrt_photon_export_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("rrt_photon_import_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 _sig("rrt_get_stats", C.c_int, C.c_void_p, C.POINTER(Stats))
 _sig("rrt_quantise", None, _f32p, C.c_size_t, _u8p)
 _sig("rrt_write_rgb_ppm", C.c_int, C.c_char_p, _f32p, C.c_uint32, C.c_uint32)
@@ -292,6 +300,41 @@ class Scene:
 
     def photon_build(self):
         check(lib.rrt_photon_build(self._h))
+
+    def photon_count(self, which):
+        n = C.c_uint64(0)
+        check(lib.rrt_photon_count(self._h, which, C.byref(n)))
+        return n.value
+
+    def photon_read(self, which):
+        n = self.photon_count(which)
+        out = {
+            "position": np.zeros((n, 3), np.float32),
+            "incident": np.zeros((n, 3), np.float32),
+            "intensity": np.zeros((n, 3), np.float32),
+            "type": np.zeros(n, np.uint8),
+            "key": np.zeros(n, np.uint64),
+        }
+        check(lib.rrt_photon_read(self._h, which, _fp(out["position"]), _fp(out["incident"]), _fp(out["intensity"]),
+                                  out["type"].ctypes.data_as(_u8p), out["key"].ctypes.data_as(_u64p)))
+        return out
+
+    def caustic_count(self, light):
+        n = C.c_uint64(0)
+        check(lib.rrt_photon_caustic_count(self._h, light, C.byref(n)))
+        return n.value
+
+    def caustic_export_device(self, light, pos4_ptr, incident4_ptr, key_ptr):
+        check(lib.rrt_photon_caustic_export_device(self._h, light, pos4_ptr, incident4_ptr, key_ptr))
+
+    def caustic_import_device(self, light, pos4_ptr, incident4_ptr, key_ptr, count):
+        check(lib.rrt_photon_caustic_import_device(self._h, light, pos4_ptr, incident4_ptr, key_ptr, count))
+
+    def photon_export_device(self, which, pos4_ptr, incident4_ptr, intensity4_ptr, meta_ptr):
+        check(lib.rrt_photon_export_device(self._h, which, pos4_ptr, incident4_ptr, intensity4_ptr, meta_ptr))
+
+    def photon_import_device(self, which, pos4_ptr, incident4_ptr, intensity4_ptr, meta_ptr, count):
+        check(lib.rrt_photon_import_device(self._h, which, pos4_ptr, incident4_ptr, intensity4_ptr, meta_ptr, count))
 
     def stats(self):
         st = Stats()

@@ -413,61 +413,67 @@ __device__ __forceinline__ void csg_eval(const DevScene &S, ObjectRange R, f3 o,
 // First entering hit with distance >= 0 over all objects; strict `<` everywhere, so the first hit in
 // list order wins inside an object and the first object wins across objects.  `tmax_init` is
 // f32::MAX for trace; shadowtrace has its own loop below.
+// The one entering hit a single-primitive object can produce (list position 0 of a plane, t0 of a
+// sphere / quadric, the cuboid's first_hit, the mesh's closest hit when it faces the ray), with the
+// reference's `distance < 0 -> skip` applied.  `mesh_bound`: only mesh hits below it are searched.
+__device__ __forceinline__ bool single_entering_hit(const DevScene &S, Instr in, f3 o, f3 d, float mesh_bound, Lds &lds, Counters &cnt,
+                                                    float &t_out, uint32_t &sub_out) {
+    sub_out = 0;
+    switch (in.op) {
+        case OP_PLANE: {
+            float t0, t1;
+            bool e0, e1;
+            if (plane_hits(S.plane_hot[in.index], o, d, t0, e0, t1, e1) == 0) return false;
+            if (t0 < 0.0f) return false;  // also the -inf entering hit of a back-facing plane
+            t_out = t0;
+            return true;
+        }
+        case OP_SPHERE: {
+            float t0, t1;
+            if (!sphere_hits(S.sphere_hot[in.index], o, d, t0, t1)) return false;
+            if (t0 < 0.0f) return false;
+            t_out = t0;
+            return true;
+        }
+        case OP_QUADRIC: {
+            float t0, t1;
+            if (!quadric_hits(S.quadric_hot[in.index], o, d, t0, t1)) return false;
+            if (t0 < 0.0f) return false;
+            t_out = t0;
+            return true;
+        }
+        case OP_CUBOID: {
+            bool hf, hb;
+            float tf, tb;
+            uint32_t sf, sb;
+            cuboid_hits(S, S.cuboid_hot[in.index], o, d, hf, tf, sf, hb, tb, sb);
+            if (!hf) return false;
+            t_out = tf;
+            sub_out = sf;
+            return true;
+        }
+        case OP_MESH: {
+            float t;
+            uint32_t slot;
+            bool ent;
+            if (!mesh_closest(S, S.meshes[in.index], o, d, mesh_bound, lds, cnt, t, slot, ent)) return false;
+            if (!ent) return false;  // a nearer back face hides farther front faces
+            t_out = t;
+            sub_out = slot;
+            return true;
+        }
+        default: return false;
+    }
+}
+
 __device__ __forceinline__ bool object_first_hit(const DevScene &S, uint32_t obj, f3 o, f3 d, float bound, Lds &lds, Counters &cnt,
                                                  float &t_out, uint32_t &instr_out, uint32_t &sub_out) {
     ObjectRange R = S.objects[obj];
     if (R.count == 1) {
         Instr in = S.instrs[R.first];
         instr_out = R.first;
-        switch (in.op) {
-            case OP_PLANE: {
-                float t0, t1;
-                bool e0, e1;
-                if (plane_hits(S.plane_hot[in.index], o, d, t0, e0, t1, e1) == 0) return false;
-                // the only entering hit is list position 0 (finite when V < 0, -inf otherwise)
-                if (t0 < 0.0f) return false;
-                t_out = t0;
-                sub_out = 0;
-                return t0 < RRT_F32_MAX;
-            }
-            case OP_SPHERE: {
-                float t0, t1;
-                if (!sphere_hits(S.sphere_hot[in.index], o, d, t0, t1)) return false;
-                if (t0 < 0.0f) return false;
-                t_out = t0;
-                sub_out = 0;
-                return t0 < RRT_F32_MAX;
-            }
-            case OP_QUADRIC: {
-                float t0, t1;
-                if (!quadric_hits(S.quadric_hot[in.index], o, d, t0, t1)) return false;
-                if (t0 < 0.0f) return false;
-                t_out = t0;
-                sub_out = 0;
-                return t0 < RRT_F32_MAX;
-            }
-            case OP_CUBOID: {
-                bool hf, hb;
-                float tf, tb;
-                uint32_t sf, sb;
-                cuboid_hits(S, S.cuboid_hot[in.index], o, d, hf, tf, sf, hb, tb, sb);
-                if (!hf) return false;
-                t_out = tf;
-                sub_out = sf;
-                return tf < RRT_F32_MAX;
-            }
-            case OP_MESH: {
-                float t;
-                uint32_t slot;
-                bool ent;
-                if (!mesh_closest(S, S.meshes[in.index], o, d, bound, lds, cnt, t, slot, ent)) return false;
-                if (!ent) return false;  // a nearer back face hides farther front faces
-                t_out = t;
-                sub_out = slot;
-                return true;
-            }
-            default: return false;
-        }
+        if (!single_entering_hit(S, in, o, d, bound, lds, cnt, t_out, sub_out)) return false;
+        return t_out < RRT_F32_MAX;  // select_first_hit starts from f32::MAX with a strict `<`
     }
     uint32_t slot, n;
     csg_eval(S, R, o, d, lds, cnt, slot, n);

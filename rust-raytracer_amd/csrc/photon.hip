@@ -1,9 +1,651 @@
-// photon.hip — photon emission / bounce tracing, photon index build (placeholder until the
-// render path is verified on hardware; replaced by the real kernels next).
+// photon.hip — the photon pass on gfx950: emission + bounce tracing into a global photon buffer
+// (environments/photon_scene.rs:42-307, lights/{point_light,directional_point_light}.rs), and the
+// build of the hash-grid index the render pass gathers from (replaces core/photon_tree.rs).
+//
+//  k_photon_shoot   one lane per emitted photon; the Russian-roulette path is a loop (every branch
+//                   of PhotonScene::photontrace is a tail call).  Each landing stores the absorbed
+//                   photon plus one shadow photon per entering surface behind it; records are
+//                   appended with one atomic per wave per destination (ballot + prefix popcount).
+//                   RNG = Philox4x32-10 keyed by (seed, light, pass, photon index): the record SET
+//                   is independent of wave scheduling, atomics order and GPU count; every record
+//                   carries a unique key so canonical order can be restored by sorting.
+//  index build      cell key per record -> rocPRIM radix sort (by record key, then stable by cell)
+//                   -> gather into cell order -> open-addressing table cell -> (first, count).
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "dev_photon.h"
+#include "dev_shade.h"
 #include "runtime.h"
+
 using namespace rrt;
-extern "C" {
-int rrt_photon_begin(rrt_scene *s, uint64_t seed) { return fail(RRT_ERR_STATE, "photon pass not built yet"); }
-int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t count) { return fail(RRT_ERR_STATE, "photon pass not built yet"); }
-int rrt_photon_build(rrt_scene *s) { return fail(RRT_ERR_STATE, "photon pass not built yet"); }
+
+namespace rrt {
+
+#define RRT_BLOCK 256
+extern __shared__ float4 g_smem_ph[];
+
+struct PhotonOut {
+    float4 *pos, *dir, *rgb;
+    uint64_t *meta;
+    uint32_t *count;
+    uint32_t capacity;
+};
+
+struct ShootArgs {
+    DevScene S;
+    PhotonOut out[2];  // regular, caustic
+    const float4 *seed_pos, *seed_dir;
+    uint32_t n_seeds;
+    uint64_t seed;
+    uint64_t first;
+    uint32_t count;
+    uint32_t light, pass;
+    uint32_t max_bounces;
+    uint32_t lds_slots;
+    uint32_t *err;  // bit 0 HitVec overflow, bit 2 shadow cap, bit 3 buffer overflow
+    unsigned long long *stats;
+};
+
+#define PH_ERR_CAPACITY 8u
+
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter) {
+    unsigned long long mask = __ballot(want);
+    if (!want) return 0xFFFFFFFFu;
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader, 64);
+    unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+    return base + (uint32_t)__popcll(mask & below);
 }
+
+__device__ __forceinline__ void store_photon(const PhotonOut &o, bool want, f3 p, f3 d, f3 c, uint32_t type, uint64_t meta, uint32_t &err) {
+    uint32_t slot = wave_append(want, o.count);
+    if (!want) return;
+    if (slot >= o.capacity) {
+        err |= PH_ERR_CAPACITY;
+        return;
+    }
+    o.pos[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(type));
+    o.dir[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+    o.rgb[slot] = make_float4(c.x, c.y, c.z, 0.0f);
+    o.meta[slot] = meta;
+}
+
+__global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
+    const DevScene &S = A.S;
+    Lds lds;
+    lds.nthreads = RRT_BLOCK;
+    lds.tid = threadIdx.x;
+    lds.lt = reinterpret_cast<float *>(g_smem_ph);
+    lds.lm = reinterpret_cast<uint32_t *>(g_smem_ph) + A.lds_slots * RRT_LIST_CAP * RRT_BLOCK;
+    lds.stack = reinterpret_cast<int *>(g_smem_ph);
+    uint32_t gid = blockIdx.x * RRT_BLOCK + threadIdx.x;
+    bool alive = gid < A.count;
+    Counters cnt = {0, 0, 0, 0};
+    uint32_t err = 0;
+    uint64_t index = A.first + gid;
+    const uint64_t tag = (uint64_t)(A.light * 2 + A.pass) << 56;
+    const DevLight L = S.lights[A.light];
+    Philox rng;
+    rng_init(rng, A.seed, A.light, A.pass, index);
+    f3 origin = L.position, dir = mk3(0, 0, 1), intensity = L.intensity;
+    if (alive) {
+        f3 direction;
+        if (A.pass == 0) {
+            if (L.kind == RRT_LIGHT_POINT) {  // point_light.rs:61-70
+                for (;;) {
+                    float x = rng_sym(rng), y = rng_sym(rng), z = rng_sym(rng);
+                    direction = mk3(x, y, z);
+                    if (lensq3(direction) <= 1.0f) break;
+                }
+            } else {  // directional_point_light.rs:68 -> Vector::random_on_surface (vector.rs:44-52)
+                direction = rng_unit_vector(rng);
+                if (dot3(direction, L.direction) < 0.0f) direction = -direction;
+            }
+        } else {  // point_light.rs:115-121 / directional_point_light.rs:108-115
+            uint32_t pick = (uint32_t)(((uint64_t)rng_u32(rng) * (uint64_t)A.n_seeds) >> 32);
+            f3 offset = rng_unit_vector(rng) * 0.1f;
+            if (L.kind == RRT_LIGHT_POINT) {
+                float4 sd = A.seed_dir[pick];
+                direction = mk3(sd.x, sd.y, sd.z) + offset;
+            } else {
+                float4 sp = A.seed_pos[pick];
+                direction = (mk3(sp.x, sp.y, sp.z) - L.position) + offset;
+            }
+        }
+        dir = norm3(direction);
+    }
+    const int dest_absorb_default = A.pass == 1 ? 1 : 0;
+    for (uint32_t bounce = 0; bounce < A.max_bounces; bounce++) {
+        if (!__any(alive)) break;
+        // PhotonScene::photontrace, photon_scene.rs:150-186
+        TraceResult tr;
+        tr.object = 0xFFFFFFFFu;
+        if (alive) trace(S, origin, dir, lds, cnt, tr);
+        if (tr.object == 0xFFFFFFFFu) alive = false;
+        HitAttr h;
+        h.position = h.normal = mk3(0, 0, 0);
+        h.material = 0;
+        h.u = h.v = 0.0f;
+        h.has_tex = false;
+        int choice = 0;
+        if (alive) {
+            eval_hit(S, origin, dir, tr.instr, tr.sub, tr.t, h);
+            const DevMaterial &M = S.materials[h.material];
+            // choose_weighted over [Absorb, Diffuse, Specular, ReflectOrRefract], photon_scene.rs:160-167
+            float c1 = M.w[0], c2 = c1 + M.w[1], c3 = c2 + M.w[2], total = c3 + M.w[3];
+            float x = rng_u01(rng) * total;
+            choice = x < c1 ? 0 : (x < c2 ? 1 : (x < c3 ? 2 : 3));
+        }
+        uint64_t key_base = tag | (index * 4096ull + (uint64_t)bounce * 64ull);
+        // absorb_photon (photon_scene.rs:188-200); retagged Caustic on ReflectOrRefract (:176)
+        bool caustic = choice == 3;
+        store_photon(A.out[0], alive && !(caustic || dest_absorb_default), h.position, dir, intensity, RRT_PHOTON_COLOUR, key_base, err);
+        store_photon(A.out[1], alive && (caustic || dest_absorb_default), h.position, dir, intensity,
+                     caustic ? RRT_PHOTON_CAUSTIC : RRT_PHOTON_COLOUR, key_base, err);
+        // shadowphotontrace, photon_scene.rs:202-228: every entering hit with d >= 0 of every object
+        {
+            f3 so = h.position + dir * 0.0001f, sd = dir;
+            uint32_t sub = 1;
+            const PhotonOut &dst = A.out[dest_absorb_default];
+            for (uint32_t obj = 0; obj < S.n_objects; obj++) {
+                ObjectRange R = S.objects[obj];
+                if (R.count == 1) {
+                    float t = 0.0f;
+                    uint32_t sb;
+                    bool have = alive && single_entering_hit(S, S.instrs[R.first], so, sd, RRT_INF, lds, cnt, t, sb);
+                    if (have && sub >= 64) {
+                        err |= RRT_ERR_BIT_SHADOW_CAP;
+                        have = false;
+                    }
+                    f3 p = isinf(t) ? mk3(0, 0, 0) : so + sd * t;
+                    store_photon(dst, have, p, sd, mk3(0, 0, 0), RRT_PHOTON_SHADOW, key_base + sub, err);
+                    if (have) sub++;
+                } else {
+                    uint32_t slot = 0, n = 0;
+                    if (alive) csg_eval(S, R, so, sd, lds, cnt, slot, n);
+                    for (uint32_t e = 0; e < RRT_LIST_CAP; e++) {
+                        bool have = false;
+                        float t = 0.0f;
+                        if (alive && e < n) {
+                            t = lds.t(slot, e);
+                            have = (lds.m(slot, e) & META_ENTER) && !(t < 0.0f);
+                        }
+                        if (!__any(have)) continue;
+                        if (have && sub >= 64) {
+                            err |= RRT_ERR_BIT_SHADOW_CAP;
+                            have = false;
+                        }
+                        f3 p = isinf(t) ? mk3(0, 0, 0) : so + sd * t;
+                        store_photon(dst, have, p, sd, mk3(0, 0, 0), RRT_PHOTON_SHADOW, key_base + sub, err);
+                        if (have) sub++;
+                    }
+                }
+            }
+        }
+        if (alive) {
+            const DevMaterial &M = S.materials[h.material];
+            if (choice == 0) {
+                alive = false;
+            } else if (choice == 1) {  // diffuse_photon, photon_scene.rs:230-251
+                f3 d = rng_unit_vector(rng);
+                if (dot3(d, h.normal) < 0.0f) d = -d;
+                f3 bounced;
+                material_bounced(S, M, h, dir, intensity, cnt, bounced);
+                origin = h.position;
+                dir = norm3(d);
+                intensity = bounced;
+            } else if (choice == 2) {  // specular_photon, photon_scene.rs:253-269
+                f3 refl = norm3(reflect3(h.normal, dir));
+                f3 bounced;
+                material_bounced(S, M, h, dir, intensity, cnt, bounced);
+                origin = h.position;
+                dir = refl;
+                intensity = bounced;
+            } else {  // reflect_or_refract_photon, photon_scene.rs:271-307
+                f3 refl = norm3(reflect3(h.normal, dir));
+                bool refract = false;
+                f3 ro, rd;
+                if (M.global_part >= 0) {
+                    const MatPart &G = M.parts[M.global_part];
+                    float kr;
+                    if (global_refraction(G, h, true, dir, ro, rd, kr)) {
+                        // refract_chance: global_material.rs:129-133, compound_material.rs:148-152
+                        float reflect = G.wr * kr;
+                        float refr = G.wt * (1.0f - kr);
+                        float chance = refr / (reflect + refr);
+                        if (M.is_compound) chance = (0.0f + chance) / (float)M.n_parts;
+                        refract = rng_u01(rng) < chance;  // gen_bool
+                    }
+                }
+                if (refract) {
+                    origin = ro;
+                    dir = rd;
+                } else {
+                    origin = h.position + refl * 0.0001f;
+                    dir = refl;
+                }
+            }
+        }
+    }
+    unsigned long long n = cnt.nodes, t = cnt.tris;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_xor(n, off, 64);
+        t += __shfl_xor(t, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n) atomicAdd(&A.stats[ST_NODES], n);
+        if (t) atomicAdd(&A.stats[ST_TRIS], t);
+    }
+    err |= cnt.overflow;
+    if (err) atomicOr(A.err, err);
+}
+
+// ---- index build kernels ------------------------------------------------------------------------------
+__global__ void k_cell_keys(const float4 *pos, uint32_t n, float inv_cell, uint64_t *keys, uint32_t *idx) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pos[i];
+    keys[i] = cell_key(cell_coord(p.x, inv_cell), cell_coord(p.y, inv_cell), cell_coord(p.z, inv_cell));
+    idx[i] = i;
+}
+__global__ void k_iota(uint32_t *idx, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = i;
+}
+template <class T>
+__global__ void k_gather(const T *src, const uint32_t *idx, uint32_t n, T *dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+// `photon.incident.normalised()` of photon_scene.rs:405 is evaluated once here instead of per query
+__global__ void k_gather_norm(const float4 *src, const uint32_t *idx, uint32_t n, float4 *dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 d = src[idx[i]];
+    f3 v = norm3(mk3(d.x, d.y, d.z));
+    dst[i] = make_float4(v.x, v.y, v.z, 0.0f);
+}
+__global__ void k_count_cells(const uint64_t *keys, uint32_t n, uint32_t *count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool start = i < n && (i == 0 || keys[i] != keys[i - 1]);
+    unsigned long long m = __ballot(start);
+    if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(count, (uint32_t)__popcll(m));
+}
+__global__ void k_fill_u64(uint64_t *p, uint32_t n, uint64_t v) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_insert_cells(const uint64_t *keys, uint32_t n, uint64_t *table_keys, uint2 *ranges, uint32_t mask) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t key = keys[i];
+    if (i != 0 && keys[i - 1] == key) return;
+    // run length by binary search for the first index whose key differs
+    uint32_t lo = i + 1, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (keys[mid] == key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    uint32_t slot = hash_key(key) & mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long *)&table_keys[slot], ~0ULL, (unsigned long long)key);
+        if (prev == ~0ULL) {
+            ranges[slot] = make_uint2(i, lo - i);
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+__global__ void k_strip_key(const uint64_t *meta, uint32_t n, uint64_t *key) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = meta[i] & 0x00FFFFFFFFFFFFFFull;
+}
+
+static inline dim3 grid_for(uint64_t n, uint32_t block = 256) { return dim3((uint32_t)((n + block - 1) / block)); }
+
+// stable radix sort of (key, index) pairs with rocPRIM
+static int sort_pairs(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in, uint32_t *idx_out, uint32_t n, hipStream_t st) {
+    size_t temp_bytes = 0;
+    RRT_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, 0, 64, st));
+    DBuf<uint8_t> temp;
+    int rc = temp.ensure(temp_bytes ? temp_bytes : 1);
+    if (rc) return rc;
+    RRT_HIP(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, 0, 64, st));
+    RRT_HIP(hipStreamSynchronize(st));
+    return RRT_OK;
+}
+
+template <class T>
+static int grow_preserve(DBuf<T> &b, size_t need, size_t used) {
+    if (need <= b.cap) return RRT_OK;
+    T *np = nullptr;
+    RRT_HIP(hipMalloc((void **)&np, need * sizeof(T)));
+    if (used && b.p) RRT_HIP(hipMemcpy(np, b.p, used * sizeof(T), hipMemcpyDeviceToDevice));
+    if (b.p) (void)hipFree(b.p);
+    b.p = np;
+    b.cap = need;
+    return RRT_OK;
+}
+static int grow_photons(PhotonBuffers &b, uint64_t need) {
+    int rc;
+    if ((rc = grow_preserve(b.pos, need, b.count)) || (rc = grow_preserve(b.dir, need, b.count)) || (rc = grow_preserve(b.rgb, need, b.count)) ||
+        (rc = grow_preserve(b.meta, need, b.count)))
+        return rc;
+    return RRT_OK;
+}
+
+// canonical order: sort the records of a buffer by meta (light, pass, key)
+static int sort_by_meta(PhotonBuffers &b) {
+    uint32_t n = (uint32_t)b.count;
+    if (n < 2) return RRT_OK;
+    DBuf<uint32_t> idx, idx2;
+    DBuf<uint64_t> k2;
+    DBuf<float4> t;
+    int rc;
+    if ((rc = idx.ensure(n)) || (rc = idx2.ensure(n)) || (rc = k2.ensure(n)) || (rc = t.ensure(n))) return rc;
+    hipLaunchKernelGGL(k_iota, grid_for(n), dim3(256), 0, nullptr, idx.p, n);
+    if ((rc = sort_pairs(b.meta.p, k2.p, idx.p, idx2.p, n, nullptr))) return rc;
+    RRT_HIP(hipMemcpy(b.meta.p, k2.p, (size_t)n * 8, hipMemcpyDeviceToDevice));
+    DBuf<float4> *arrs[3] = {&b.pos, &b.dir, &b.rgb};
+    for (auto *a : arrs) {
+        hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, a->p, idx2.p, n, t.p);
+        RRT_HIP(hipMemcpy(a->p, t.p, (size_t)n * 16, hipMemcpyDeviceToDevice));
+    }
+    return RRT_OK;
+}
+
+static int build_index(rrt_scene *s, int which) {
+    PhotonBuffers &b = s->local[which];
+    PhotonIndex &X = s->index[which];
+    uint32_t n = (uint32_t)b.count;
+    X.count = n;
+    X.inv_cell = 1.0f / (2.0f * s->params.gather_half_width);
+    X.table_size = 0;
+    if (n == 0) return RRT_OK;
+    int rc;
+    if ((rc = sort_by_meta(b))) return rc;  // canonical order first; the cell sort below is stable
+    DBuf<uint64_t> keys, keys2;
+    DBuf<uint32_t> idx, idx2, ncell;
+    if ((rc = keys.ensure(n)) || (rc = keys2.ensure(n)) || (rc = idx.ensure(n)) || (rc = idx2.ensure(n)) || (rc = ncell.ensure(1))) return rc;
+    hipLaunchKernelGGL(k_cell_keys, grid_for(n), dim3(256), 0, nullptr, b.pos.p, n, X.inv_cell, keys.p, idx.p);
+    if ((rc = sort_pairs(keys.p, keys2.p, idx.p, idx2.p, n, nullptr))) return rc;
+    if ((rc = X.pos.ensure(n)) || (rc = X.dir.ensure(n)) || (rc = X.rgb.ensure(n))) return rc;
+    hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.pos.p, idx2.p, n, X.pos.p);
+    hipLaunchKernelGGL(k_gather_norm, grid_for(n), dim3(256), 0, nullptr, b.dir.p, idx2.p, n, X.dir.p);
+    hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.rgb.p, idx2.p, n, X.rgb.p);
+    RRT_HIP(hipMemset(ncell.p, 0, 4));
+    hipLaunchKernelGGL(k_count_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, ncell.p);
+    uint32_t cells = 0;
+    RRT_HIP(hipMemcpy(&cells, ncell.p, 4, hipMemcpyDeviceToHost));
+    uint32_t size = 64;
+    while (size < 2 * cells) size <<= 1;
+    if ((rc = X.keys.ensure(size)) || (rc = X.ranges.ensure(size))) return rc;
+    X.table_size = size;
+    hipLaunchKernelGGL(k_fill_u64, grid_for(size), dim3(256), 0, nullptr, X.keys.p, size, ~0ULL);
+    hipLaunchKernelGGL(k_insert_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, X.keys.p, X.ranges.p, size - 1);
+    RRT_HIP(hipGetLastError());
+    RRT_HIP(hipDeviceSynchronize());
+    return RRT_OK;
+}
+
+static int rebuild_seeds(rrt_scene *s, int light, const float4 *pos, const float4 *dir, const uint64_t *key, uint64_t count) {
+    CausticSeeds &cs = *s->seeds[light];
+    uint32_t n = (uint32_t)count;
+    cs.count = n;
+    if (n == 0) return RRT_OK;
+    int rc;
+    DBuf<uint32_t> idx, idx2;
+    DBuf<uint64_t> k2;
+    if ((rc = idx.ensure(n)) || (rc = idx2.ensure(n)) || (rc = k2.ensure(n))) return rc;
+    if ((rc = cs.pos.ensure(n)) || (rc = cs.dir.ensure(n)) || (rc = cs.key.ensure(n))) return rc;
+    hipLaunchKernelGGL(k_iota, grid_for(n), dim3(256), 0, nullptr, idx.p, n);
+    if ((rc = sort_pairs(key, k2.p, idx.p, idx2.p, n, nullptr))) return rc;
+    hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, pos, idx2.p, n, cs.pos.p);
+    hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, dir, idx2.p, n, cs.dir.p);
+    RRT_HIP(hipMemcpy(cs.key.p, k2.p, (size_t)n * 8, hipMemcpyDeviceToDevice));
+    RRT_HIP(hipDeviceSynchronize());
+    return RRT_OK;
+}
+
+}  // namespace rrt
+
+extern "C" {
+
+int rrt_photon_begin(rrt_scene *s, uint64_t seed) {
+    if (!s) return fail(RRT_ERR_INVALID, "null scene");
+    if (s->mode != RRT_MODE_PHOTON) return fail(RRT_ERR_STATE, "scene is not a PhotonScene");
+    for (const rrt_light_desc &l : s->lights)
+        if (l.kind == RRT_LIGHT_DIRECTIONAL) return fail(RRT_ERR_INVALID, "Light does not support photon mapping");  // light.rs:16-18
+    int rc = flatten_scene(s);
+    if (rc) return rc;
+    s->seed = seed;
+    s->maps_built = false;
+    s->local[0].count = s->local[1].count = 0;
+    s->seeds.clear();
+    for (size_t i = 0; i < s->lights.size(); i++) s->seeds.push_back(std::make_unique<CausticSeeds>());
+    s->stats.photons_emitted = 0;
+    s->stats.ms_photon_shoot = 0;
+    s->stats.ms_photon_build = 0;
+    return RRT_OK;
+}
+
+int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t count) {
+    if (!s) return fail(RRT_ERR_INVALID, "null scene");
+    if (!s->flattened || s->seeds.size() != s->lights.size()) return fail(RRT_ERR_STATE, "rrt_photon_begin has not been called");
+    if (light < 0 || light >= (int)s->lights.size() || pass < 0 || pass > 1) return fail(RRT_ERR_INVALID, "bad light/pass");
+    if (count == 0) return RRT_OK;
+    if (count >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 photons in one call");
+    if (first + count >= (1ull << 40)) return fail(RRT_ERR_LIMIT, "photon index above 2^40");
+    CausticSeeds &cs = *s->seeds[light];
+    if (pass == 1 && cs.count == 0) {
+        // point_light.rs:106-108 returns an empty Vec; directional_point_light.rs:110 would panic on unwrap
+        if (s->lights[light].kind == RRT_LIGHT_DIRPOINT) return fail(RRT_ERR_INVALID, "no caustic photons to aim at (reference: unwrap on None)");
+        return RRT_OK;
+    }
+    int rc;
+    DBuf<uint32_t> counts;
+    if ((rc = counts.ensure(2))) return rc;
+    double est[2] = {pass == 0 ? 4.0 : 0.0, pass == 0 ? 1.0 : 5.0};
+    hipEvent_t e0 = s->events[0], e1 = s->events[1];
+    for (int attempt = 0; attempt < 8; attempt++) {
+        uint64_t need[2];
+        for (int w = 0; w < 2; w++) {
+            need[w] = s->local[w].count + (uint64_t)(est[w] * (double)count) + 4096;
+            if (need[w] >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
+            if ((rc = grow_photons(s->local[w], need[w]))) return rc;
+        }
+        uint32_t init[2] = {(uint32_t)s->local[0].count, (uint32_t)s->local[1].count};
+        RRT_HIP(hipMemcpy(counts.p, init, sizeof(init), hipMemcpyHostToDevice));
+        RRT_HIP(hipMemset(s->counters.p + 63, 0, 4));
+        RRT_HIP(hipMemset(s->stats_dev.p, 0, ST_COUNT * sizeof(unsigned long long)));
+        ShootArgs A;
+        memset(&A, 0, sizeof(A));
+        A.S = s->dev.view;
+        for (int w = 0; w < 2; w++) {
+            A.out[w].pos = s->local[w].pos.p;
+            A.out[w].dir = s->local[w].dir.p;
+            A.out[w].rgb = s->local[w].rgb.p;
+            A.out[w].meta = s->local[w].meta.p;
+            A.out[w].count = counts.p + w;
+            A.out[w].capacity = (uint32_t)std::min<uint64_t>(s->local[w].pos.cap, 0xFFFFFFFFull);
+        }
+        A.seed_pos = cs.pos.p;
+        A.seed_dir = cs.dir.p;
+        A.n_seeds = (uint32_t)cs.count;
+        A.seed = s->seed;
+        A.first = first;
+        A.count = (uint32_t)count;
+        A.light = (uint32_t)light;
+        A.pass = (uint32_t)pass;
+        A.max_bounces = s->params.max_photon_bounces;
+        A.lds_slots = s->dev.lds_slots;
+        A.err = s->counters.p + 63;
+        A.stats = s->stats_dev.p;
+        RRT_HIP(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(k_photon_shoot, grid_for(count, RRT_BLOCK), dim3(RRT_BLOCK), s->dev.lds_bytes, nullptr, A);
+        RRT_HIP(hipEventRecord(e1, nullptr));
+        RRT_HIP(hipGetLastError());
+        RRT_HIP(hipDeviceSynchronize());
+        float ms = 0.0f;
+        RRT_HIP(hipEventElapsedTime(&ms, e0, e1));
+        uint32_t err = 0, got[2];
+        RRT_HIP(hipMemcpy(&err, s->counters.p + 63, 4, hipMemcpyDeviceToHost));
+        RRT_HIP(hipMemcpy(got, counts.p, sizeof(got), hipMemcpyDeviceToHost));
+        if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
+        if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
+        if (err & 4u) return fail(RRT_ERR_LIMIT, "more than 63 shadow photons behind one landing");
+        if (err & PH_ERR_CAPACITY) {  // rerun with room for what this attempt wanted to store
+            for (int w = 0; w < 2; w++) est[w] = std::max(est[w] * 1.5, 1.25 * (double)(got[w] - init[w]) / (double)count);
+            continue;
+        }
+        s->stats.ms_photon_shoot += ms;
+        s->stats.photons_emitted += count;
+        uint64_t caustic_before = s->local[1].count;
+        s->local[0].count = got[0];
+        s->local[1].count = got[1];
+        unsigned long long st[ST_COUNT];
+        RRT_HIP(hipMemcpy(st, s->stats_dev.p, sizeof(st), hipMemcpyDeviceToHost));
+        s->stats.bvh_nodes_visited = st[ST_NODES];
+        s->stats.bvh_tris_tested = st[ST_TRIS];
+        if (pass == 0) {
+            // photon_scene.rs:48-57: the Caustic-tagged records of pass 1 are what pass 2 aims at.  Everything
+            // this call appended to the caustic buffer is Caustic-tagged; merge with earlier ranges.
+            uint64_t add = got[1] - caustic_before;
+            uint64_t total = cs.count + add;
+            DBuf<float4> p, d;
+            DBuf<uint64_t> k;
+            if ((rc = p.ensure(total ? total : 1)) || (rc = d.ensure(total ? total : 1)) || (rc = k.ensure(total ? total : 1))) return rc;
+            if (cs.count) {
+                RRT_HIP(hipMemcpy(p.p, cs.pos.p, cs.count * 16, hipMemcpyDeviceToDevice));
+                RRT_HIP(hipMemcpy(d.p, cs.dir.p, cs.count * 16, hipMemcpyDeviceToDevice));
+                RRT_HIP(hipMemcpy(k.p, cs.key.p, cs.count * 8, hipMemcpyDeviceToDevice));
+            }
+            if (add) {
+                RRT_HIP(hipMemcpy(p.p + cs.count, s->local[1].pos.p + caustic_before, add * 16, hipMemcpyDeviceToDevice));
+                RRT_HIP(hipMemcpy(d.p + cs.count, s->local[1].dir.p + caustic_before, add * 16, hipMemcpyDeviceToDevice));
+                hipLaunchKernelGGL(k_strip_key, grid_for(add), dim3(256), 0, nullptr, s->local[1].meta.p + caustic_before, (uint32_t)add, k.p + cs.count);
+            }
+            if ((rc = rebuild_seeds(s, light, p.p, d.p, k.p, total))) return rc;
+        }
+        return RRT_OK;
+    }
+    return fail(RRT_ERR_LIMIT, "photon buffer kept overflowing");
+}
+
+int rrt_photon_build(rrt_scene *s) {
+    if (!s) return fail(RRT_ERR_INVALID, "null scene");
+    if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_photon_begin has not been called");
+    hipEvent_t e0 = s->events[0], e1 = s->events[1];
+    RRT_HIP(hipEventRecord(e0, nullptr));
+    int rc;
+    for (int w = 0; w < 2; w++)
+        if ((rc = build_index(s, w))) return rc;
+    RRT_HIP(hipEventRecord(e1, nullptr));
+    RRT_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    RRT_HIP(hipEventElapsedTime(&ms, e0, e1));
+    s->stats.ms_photon_build = ms;
+    s->stats.photons_stored_regular = s->local[0].count;
+    s->stats.photons_stored_caustic = s->local[1].count;
+    s->maps_built = true;
+    return RRT_OK;
+}
+
+int rrt_photon_count(rrt_scene *s, int which, uint64_t *count) {
+    if (!s || !count || which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad argument");
+    *count = s->local[which].count;
+    return RRT_OK;
+}
+
+int rrt_photon_read(rrt_scene *s, int which, float *position, float *incident, float *intensity, uint8_t *type, uint64_t *key) {
+    if (!s || which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad argument");
+    PhotonBuffers &b = s->local[which];
+    size_t n = b.count;
+    if (n == 0) return RRT_OK;
+    int rc = sort_by_meta(b);
+    if (rc) return rc;
+    std::vector<float4> tmp(n);
+    auto pull = [&](const float4 *src, float *dst, uint8_t *ty) -> int {
+        RRT_HIP(hipMemcpy(tmp.data(), src, n * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) {
+            if (dst) {
+                dst[i * 3] = tmp[i].x; dst[i * 3 + 1] = tmp[i].y; dst[i * 3 + 2] = tmp[i].z;
+            }
+            if (ty) {
+                uint32_t t;
+                memcpy(&t, &tmp[i].w, 4);
+                ty[i] = (uint8_t)t;
+            }
+        }
+        return RRT_OK;
+    };
+    if ((position || type) && (rc = pull(b.pos.p, position, type))) return rc;
+    if (incident && (rc = pull(b.dir.p, incident, nullptr))) return rc;
+    if (intensity && (rc = pull(b.rgb.p, intensity, nullptr))) return rc;
+    if (key) RRT_HIP(hipMemcpy(key, b.meta.p, n * 8, hipMemcpyDeviceToHost));
+    return RRT_OK;
+}
+
+// ---- multi-GPU exchange points: plain device pointers in, plain device pointers out ----
+int rrt_photon_caustic_count(rrt_scene *s, int light, uint64_t *count) {
+    if (!s || !count || light < 0 || light >= (int)s->seeds.size()) return fail(RRT_ERR_INVALID, "bad argument");
+    *count = s->seeds[light]->count;
+    return RRT_OK;
+}
+int rrt_photon_caustic_export_device(rrt_scene *s, int light, float *pos4_dev, float *incident4_dev, uint64_t *key_dev) {
+    if (!s || light < 0 || light >= (int)s->seeds.size() || !pos4_dev || !incident4_dev || !key_dev) return fail(RRT_ERR_INVALID, "bad argument");
+    CausticSeeds &cs = *s->seeds[light];
+    if (cs.count == 0) return RRT_OK;
+    RRT_HIP(hipMemcpy(pos4_dev, cs.pos.p, cs.count * 16, hipMemcpyDeviceToDevice));
+    RRT_HIP(hipMemcpy(incident4_dev, cs.dir.p, cs.count * 16, hipMemcpyDeviceToDevice));
+    RRT_HIP(hipMemcpy(key_dev, cs.key.p, cs.count * 8, hipMemcpyDeviceToDevice));
+    return RRT_OK;
+}
+int rrt_photon_caustic_import_device(rrt_scene *s, int light, const float *pos4_dev, const float *incident4_dev, const uint64_t *key_dev,
+                                     uint64_t count) {
+    if (!s || light < 0 || light >= (int)s->seeds.size()) return fail(RRT_ERR_INVALID, "bad argument");
+    if (count && (!pos4_dev || !incident4_dev || !key_dev)) return fail(RRT_ERR_INVALID, "null argument");
+    if (count >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "too many caustic seeds");
+    return rebuild_seeds(s, light, (const float4 *)pos4_dev, (const float4 *)incident4_dev, key_dev, count);
+}
+int rrt_photon_local_count(rrt_scene *s, int which, uint64_t *count) { return rrt_photon_count(s, which, count); }
+int rrt_photon_export_device(rrt_scene *s, int which, float *pos4_dev, float *incident4_dev, float *intensity4_dev, uint64_t *meta_dev) {
+    if (!s || which < 0 || which > 1 || !pos4_dev || !incident4_dev || !intensity4_dev || !meta_dev) return fail(RRT_ERR_INVALID, "bad argument");
+    PhotonBuffers &b = s->local[which];
+    if (b.count == 0) return RRT_OK;
+    RRT_HIP(hipMemcpy(pos4_dev, b.pos.p, b.count * 16, hipMemcpyDeviceToDevice));
+    RRT_HIP(hipMemcpy(incident4_dev, b.dir.p, b.count * 16, hipMemcpyDeviceToDevice));
+    RRT_HIP(hipMemcpy(intensity4_dev, b.rgb.p, b.count * 16, hipMemcpyDeviceToDevice));
+    RRT_HIP(hipMemcpy(meta_dev, b.meta.p, b.count * 8, hipMemcpyDeviceToDevice));
+    return RRT_OK;
+}
+int rrt_photon_import_device(rrt_scene *s, int which, const float *pos4_dev, const float *incident4_dev, const float *intensity4_dev,
+                             const uint64_t *meta_dev, uint64_t count) {
+    if (!s || which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad argument");
+    if (count && (!pos4_dev || !incident4_dev || !intensity4_dev || !meta_dev)) return fail(RRT_ERR_INVALID, "null argument");
+    if (count >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
+    PhotonBuffers &b = s->local[which];
+    b.count = 0;
+    int rc = grow_photons(b, count ? count : 1);
+    if (rc) return rc;
+    if (count) {
+        RRT_HIP(hipMemcpy(b.pos.p, pos4_dev, count * 16, hipMemcpyDeviceToDevice));
+        RRT_HIP(hipMemcpy(b.dir.p, incident4_dev, count * 16, hipMemcpyDeviceToDevice));
+        RRT_HIP(hipMemcpy(b.rgb.p, intensity4_dev, count * 16, hipMemcpyDeviceToDevice));
+        RRT_HIP(hipMemcpy(b.meta.p, meta_dev, count * 8, hipMemcpyDeviceToDevice));
+    }
+    b.count = count;
+    s->maps_built = false;
+    return RRT_OK;
+}
+
+}  // extern "C"
