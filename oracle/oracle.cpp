@@ -1349,7 +1349,7 @@ int orc_photon_shoot(orc_scene *s, int light, int pass, uint64_t first, uint64_t
     for (auto &v : per_thread)
         for (Photon &p : v) {
             bool to_caustic = pass == 1 || p.type == PT_CAUSTIC;  // photon_scene.rs:48-65
-            if (pass == 0 && p.type == PT_CAUSTIC) e.caustic_seeds[light].push_back(p);
+            if (pass == 0 && p.type == PT_CAUSTIC) e.caustic_seeds[light].push_back(p);  // key without the (light, pass) tag
             p.key = photon_meta(light, pass, p.key);
             e.local[to_caustic ? 1 : 0].push_back(p);
         }
@@ -1404,6 +1404,59 @@ int orc_photon_read(orc_scene *s, int which, float *position, float *incident, f
     }
     return RRT_OK;
 }
+// exchange points for multi-rank tests (host arrays; the product's versions take device pointers)
+int orc_photon_caustic_count(orc_scene *s, int light, uint64_t *count) {
+    if (light < 0 || light >= (int)s->env.caustic_seeds.size()) return fail(RRT_ERR_INVALID, "bad light");
+    *count = s->env.caustic_seeds[light].size();
+    return RRT_OK;
+}
+int orc_photon_caustic_export(orc_scene *s, int light, float *pos4, float *incident4, uint64_t *key) {
+    if (light < 0 || light >= (int)s->env.caustic_seeds.size()) return fail(RRT_ERR_INVALID, "bad light");
+    const auto &v = s->env.caustic_seeds[light];
+    for (size_t i = 0; i < v.size(); i++) {
+        pos4[i * 4] = v[i].position.x; pos4[i * 4 + 1] = v[i].position.y; pos4[i * 4 + 2] = v[i].position.z; pos4[i * 4 + 3] = 0.0f;
+        incident4[i * 4] = v[i].incident.x; incident4[i * 4 + 1] = v[i].incident.y; incident4[i * 4 + 2] = v[i].incident.z; incident4[i * 4 + 3] = 0.0f;
+        key[i] = v[i].key;
+    }
+    return RRT_OK;
+}
+int orc_photon_caustic_import(orc_scene *s, int light, const float *pos4, const float *incident4, const uint64_t *key, uint64_t count) {
+    if (light < 0 || light >= (int)s->env.caustic_seeds.size()) return fail(RRT_ERR_INVALID, "bad light");
+    auto &v = s->env.caustic_seeds[light];
+    v.clear();
+    for (uint64_t i = 0; i < count; i++)
+        v.push_back(Photon{V3{pos4[i * 4], pos4[i * 4 + 1], pos4[i * 4 + 2]}, V3{incident4[i * 4], incident4[i * 4 + 1], incident4[i * 4 + 2]},
+                           black(), PT_CAUSTIC, key[i]});
+    std::sort(v.begin(), v.end(), [](const Photon &a, const Photon &b) { return a.key < b.key; });
+    return RRT_OK;
+}
+int orc_photon_export(orc_scene *s, int which, float *pos4, float *incident4, float *intensity4, uint64_t *meta) {
+    if (which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad map");
+    const auto &v = s->env.local[which];
+    for (size_t i = 0; i < v.size(); i++) {
+        uint32_t ty = v[i].type;
+        pos4[i * 4] = v[i].position.x; pos4[i * 4 + 1] = v[i].position.y; pos4[i * 4 + 2] = v[i].position.z;
+        memcpy(&pos4[i * 4 + 3], &ty, 4);
+        incident4[i * 4] = v[i].incident.x; incident4[i * 4 + 1] = v[i].incident.y; incident4[i * 4 + 2] = v[i].incident.z; incident4[i * 4 + 3] = 0.0f;
+        intensity4[i * 4] = v[i].intensity.r; intensity4[i * 4 + 1] = v[i].intensity.g; intensity4[i * 4 + 2] = v[i].intensity.b; intensity4[i * 4 + 3] = 0.0f;
+        meta[i] = v[i].key;
+    }
+    return RRT_OK;
+}
+int orc_photon_import(orc_scene *s, int which, const float *pos4, const float *incident4, const float *intensity4, const uint64_t *meta, uint64_t count) {
+    if (which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad map");
+    auto &v = s->env.local[which];
+    v.clear();
+    for (uint64_t i = 0; i < count; i++) {
+        uint32_t ty;
+        memcpy(&ty, &pos4[i * 4 + 3], 4);
+        v.push_back(Photon{V3{pos4[i * 4], pos4[i * 4 + 1], pos4[i * 4 + 2]}, V3{incident4[i * 4], incident4[i * 4 + 1], incident4[i * 4 + 2]},
+                           Colour{intensity4[i * 4], intensity4[i * 4 + 1], intensity4[i * 4 + 2]}, (uint8_t)ty, meta[i]});
+    }
+    s->env.maps_built = false;
+    return RRT_OK;
+}
+
 int orc_photon_query(orc_scene *s, int which, const float p[3], float r, uint64_t *k, float dir_sum[3], float intensity_sum[3]) {
     if (which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad map");
     V3 pos{p[0], p[1], p[2]};

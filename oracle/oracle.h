@@ -59,6 +59,13 @@ int orc_photon_build(orc_scene *s);
 int orc_photon_count(orc_scene *s, int which, uint64_t *count);
 int orc_photon_read(orc_scene *s, int which, float *position, float *incident, float *intensity,
                     uint8_t *type, uint64_t *key);
+/* exchange points for multi-rank tests: [n][4] f32 host arrays (pos4.w = photon type bits), u64 keys */
+int orc_photon_caustic_count(orc_scene *s, int light, uint64_t *count);
+int orc_photon_caustic_export(orc_scene *s, int light, float *pos4, float *incident4, uint64_t *key);
+int orc_photon_caustic_import(orc_scene *s, int light, const float *pos4, const float *incident4, const uint64_t *key, uint64_t count);
+int orc_photon_export(orc_scene *s, int which, float *pos4, float *incident4, float *intensity4, uint64_t *meta);
+int orc_photon_import(orc_scene *s, int which, const float *pos4, const float *incident4, const float *intensity4, const uint64_t *meta,
+                      uint64_t count);
 /* brute-force closed-box query used to validate the index: returns K and sums */
 int orc_photon_query(orc_scene *s, int which, const float p[3], float half_width, uint64_t *k,
                      float dir_sum[3], float intensity_sum[3]);

@@ -36,6 +36,13 @@ def _load():
             "librrt.so is not built (%s): run `make -C rust-raytracer_amd/csrc` or __graft_entry__.build(); "
             "there is no CPU fallback" % LIB_PATH
         )
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64, and whichever copy is loaded first
+    # serves everybody.  Loading torch's first keeps torch.distributed / torch.cuda and librrt on the same runtime
+    # (the other order leaves librrt without a visible device on this image).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     return C.CDLL(LIB_PATH)
 
 
@@ -188,7 +195,7 @@ class Scene:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib.rrt_scene_destroy(h)
 
     @classmethod

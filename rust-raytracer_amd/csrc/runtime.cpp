@@ -17,9 +17,11 @@ namespace rrt {
 
 int LevelStorage::ensure(uint32_t n, uint32_t n_lights, bool need_rays) {
     if (n == 0) n = 1;
-    if (n <= capacity) return RRT_OK;
-    uint32_t cap = n + n / 8 + 256;
+    uint32_t cap = capacity;
+    if (n > capacity) cap = n + n / 8 + 256;
     int rc = RRT_OK;
+    // every array is checked on every call: the ray arrays are only needed by levels that read stored rays, and a
+    // level first used with camera-generated rays may later be fed explicit ones (rrt_raytrace)
     if (need_rays) {
         if ((rc = ray_o.ensure(cap))) return rc;
         if ((rc = ray_d.ensure(cap))) return rc;

@@ -62,6 +62,11 @@ _sig("orc_photon_shoot", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_
 _sig("orc_photon_build", C.c_int, C.c_void_p)
 _sig("orc_photon_count", C.c_int, C.c_void_p, C.c_int, _u64p)
 _sig("orc_photon_read", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _f32p, _u8p, _u64p)
+_sig("orc_photon_caustic_count", C.c_int, C.c_void_p, C.c_int, _u64p)
+_sig("orc_photon_caustic_export", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _u64p)
+_sig("orc_photon_caustic_import", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _u64p, C.c_uint64)
+_sig("orc_photon_export", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _f32p, _u64p)
+_sig("orc_photon_import", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _f32p, _u64p, C.c_uint64)
 _sig("orc_photon_query", C.c_int, C.c_void_p, C.c_int, _f32p, C.c_float, _u64p, _f32p, _f32p)
 _sig("orc_get_stats", C.c_int, C.c_void_p, C.POINTER(abi.Stats))
 _sig("orc_quantise", None, _f32p, C.c_size_t, _u8p)
@@ -111,7 +116,7 @@ class OracleScene:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib.orc_scene_destroy(h)
 
     @classmethod
@@ -129,6 +134,41 @@ class OracleScene:
 
     def builder(self):
         return lib.orc_scene_builder(self._h)
+
+    # the same construction verbs as rrt.Scene, routed through the oracle's rrt_builder vtable
+    def _vt(self):
+        if not hasattr(self, "_vtable"):
+            b = C.cast(self.builder(), C.POINTER(abi.Builder)).contents
+            V = C.c_void_p
+            self._ctx = b.ctx
+            self._vtable = dict(
+                add_texture=C.CFUNCTYPE(C.c_int, V, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p)(b.add_texture),
+                add_material=C.CFUNCTYPE(C.c_int, V, C.POINTER(abi.MaterialDesc))(b.add_material),
+                object_define=C.CFUNCTYPE(C.c_int, V, C.POINTER(abi.ObjectDesc))(b.object_define),
+                object_transform=C.CFUNCTYPE(C.c_int, V, C.c_int, _f32p)(b.object_transform),
+                add_object=C.CFUNCTYPE(C.c_int, V, C.c_int)(b.add_object),
+                add_light=C.CFUNCTYPE(C.c_int, V, C.POINTER(abi.LightDesc))(b.add_light),
+            )
+        return self._vtable
+
+    def add_texture(self, width, height, maxval, samples):
+        return check(self._vt()["add_texture"](self._ctx, width, height, maxval, bytes(samples)))
+
+    def add_material(self, desc):
+        return check(self._vt()["add_material"](self._ctx, C.byref(desc)))
+
+    def object_define(self, desc):
+        return check(self._vt()["object_define"](self._ctx, C.byref(desc)))
+
+    def object_transform(self, handle, m16):
+        m = _f32(m16, (16,))
+        check(self._vt()["object_transform"](self._ctx, handle, _fp(m)))
+
+    def add_object(self, handle):
+        return check(self._vt()["add_object"](self._ctx, handle))
+
+    def add_light(self, desc):
+        return check(self._vt()["add_light"](self._ctx, C.byref(desc)))
 
     @property
     def mode(self):
@@ -221,6 +261,33 @@ class OracleScene:
         }
         check(lib.orc_photon_read(self._h, which, _fp(out["position"]), _fp(out["incident"]), _fp(out["intensity"]), out["type"].ctypes.data_as(_u8p), out["key"].ctypes.data_as(_u64p)))
         return out
+
+    def caustic_count(self, light):
+        n = C.c_uint64(0)
+        check(lib.orc_photon_caustic_count(self._h, light, C.byref(n)))
+        return n.value
+
+    def caustic_export(self, light):
+        n = self.caustic_count(light)
+        pos, inc, key = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.uint64)
+        check(lib.orc_photon_caustic_export(self._h, light, _fp(pos), _fp(inc), key.ctypes.data_as(_u64p)))
+        return pos, inc, key
+
+    def caustic_import(self, light, pos, inc, key):
+        pos, inc = _f32(pos, (-1, 4)), _f32(inc, (-1, 4))
+        key = np.ascontiguousarray(key, np.uint64)
+        check(lib.orc_photon_caustic_import(self._h, light, _fp(pos), _fp(inc), key.ctypes.data_as(_u64p), pos.shape[0]))
+
+    def photon_export(self, which):
+        n = self.photon_count(which)
+        pos, inc, rgb, meta = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.uint64)
+        check(lib.orc_photon_export(self._h, which, _fp(pos), _fp(inc), _fp(rgb), meta.ctypes.data_as(_u64p)))
+        return pos, inc, rgb, meta
+
+    def photon_import(self, which, pos, inc, rgb, meta):
+        pos, inc, rgb = _f32(pos, (-1, 4)), _f32(inc, (-1, 4)), _f32(rgb, (-1, 4))
+        meta = np.ascontiguousarray(meta, np.uint64)
+        check(lib.orc_photon_import(self._h, which, _fp(pos), _fp(inc), _fp(rgb), meta.ctypes.data_as(_u64p), pos.shape[0]))
 
     def photon_query(self, which, p, half_width):
         p = _f32(p)

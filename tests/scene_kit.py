@@ -1,0 +1,150 @@
+"""Small scene-building helpers shared by oracle tests and GPU parity tests.
+
+Every helper takes a scene object that has the construction verbs of the C ABI
+(add_material / object_define / object_transform / add_object / add_light): both
+rrt.Scene (the product) and oracle_binding.OracleScene (the checker) do.
+"""
+import importlib
+
+import numpy as np
+
+rrt = importlib.import_module("rust-raytracer_amd")
+abi = rrt._abi
+
+
+def monochrome(scene, colour=(1.0, 0.0, 0.0), ambient=0.1, shininess=100.0):
+    d = abi.MaterialDesc()
+    d.kind = abi.MAT_MONOCHROME
+    d.colour[:] = colour
+    d.ambient, d.shininess = ambient, shininess
+    d.diffuse_tex = d.normal_tex = -1
+    return scene.add_material(d)
+
+
+def global_material(scene, reflect, refract, ior):
+    d = abi.MaterialDesc()
+    d.kind = abi.MAT_GLOBAL
+    d.reflect_weight, d.refract_weight, d.ior = reflect, refract, ior
+    d.diffuse_tex = d.normal_tex = -1
+    return scene.add_material(d)
+
+
+def falsecolour(scene):
+    d = abi.MaterialDesc()
+    d.kind = abi.MAT_FALSECOLOUR
+    d.diffuse_tex = d.normal_tex = -1
+    return scene.add_material(d)
+
+
+def texture_material(scene, diffuse, normal=-1, scale=1.0, ambient=0.1, shininess=100.0):
+    d = abi.MaterialDesc()
+    d.kind = abi.MAT_TEXTURE
+    d.diffuse_tex, d.normal_tex = diffuse, normal
+    d.scale, d.ambient, d.shininess = scale, ambient, shininess
+    return scene.add_material(d)
+
+
+def compound(scene, parts):
+    d = abi.MaterialDesc()
+    d.kind = abi.MAT_COMPOUND
+    d.diffuse_tex = d.normal_tex = -1
+    d.n_parts = len(parts)
+    for i, p in enumerate(parts):
+        d.parts[i] = p
+    return scene.add_material(d)
+
+
+def _obj(kind, material, values):
+    d = abi.ObjectDesc()
+    d.kind = kind
+    d.material = material
+    for i, v in enumerate(values):
+        d.v[i] = v
+    return d
+
+
+def plane(scene, point, up, normal, material):
+    return scene.object_define(_obj(abi.OBJ_PLANE, material, list(point) + list(up) + list(normal)))
+
+
+def sphere(scene, centre, radius, material):
+    return scene.object_define(_obj(abi.OBJ_SPHERE, material, list(centre) + [radius]))
+
+
+def cuboid(scene, corner, size, material):
+    return scene.object_define(_obj(abi.OBJ_CUBOID, material, list(corner) + list(size)))
+
+
+def quadric(scene, coeffs, material):
+    return scene.object_define(_obj(abi.OBJ_QUADRATIC, material, list(coeffs)))
+
+
+def csg(scene, mode, left, right):
+    d = abi.ObjectDesc()
+    d.kind = abi.OBJ_CSG
+    d.material = -1
+    d.csg_mode, d.left, d.right = mode, left, right
+    return scene.object_define(d)
+
+
+def mesh(scene, positions, normals, material, smooth):
+    import ctypes as C
+
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3, 3)
+    d = abi.ObjectDesc()
+    d.kind = abi.OBJ_MESH
+    d.material = material
+    d.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
+    if normals is not None:
+        nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3, 3)
+        d.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))
+    d.n_triangles = pos.shape[0]
+    d.smooth = int(smooth)
+    return scene.object_define(d)
+
+
+def translation(t):
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 3] = t
+    return m
+
+
+def scaling(s):
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0] = m[1, 1] = m[2, 2] = s
+    return m
+
+
+def light(scene, kind, position=(0, 0, 0), direction=(0, 0, 0), colour=(1, 1, 1)):
+    d = abi.LightDesc()
+    d.kind = kind
+    d.position[:] = position
+    d.direction[:] = direction
+    d.colour[:] = colour
+    return scene.add_light(d)
+
+
+def random_rays(n, seed, origin_scale=6.0, towards=(0.0, 1.0, 4.0), spread=4.0):
+    """Rays from random origins aimed at random points near `towards` (plus some axis-parallel ones)."""
+    rng = np.random.default_rng(seed)
+    o = (rng.random((n, 3), dtype=np.float32) - 0.5) * 2 * origin_scale
+    t = np.asarray(towards, np.float32) + (rng.random((n, 3), dtype=np.float32) - 0.5) * 2 * spread
+    d = t - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k = n // 16
+    axes = np.eye(3, dtype=np.float32)[rng.integers(0, 3, k)] * rng.choice([-1.0, 1.0], (k, 1)).astype(np.float32)
+    d[:k] = axes
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+def teapot_grid(obj_pos, obj_nrm, nx, ny, spacing=30.0):
+    """Deterministic big mesh: an nx x ny grid of copies of a base mesh (BASELINE config 4 generator)."""
+    pos = np.asarray(obj_pos, np.float32).reshape(-1, 3, 3)
+    outs, outn = [], []
+    for j in range(ny):
+        for i in range(nx):
+            off = np.array([(i - (nx - 1) / 2) * spacing, 0.0, (j - (ny - 1) / 2) * spacing], np.float32)
+            outs.append(pos + off)
+            if obj_nrm is not None:
+                outn.append(np.asarray(obj_nrm, np.float32).reshape(-1, 3, 3))
+    return np.concatenate(outs), (np.concatenate(outn) if outn else None)

@@ -1,0 +1,289 @@
+"""GPU parity tests: librrt (HIP, through the C ABI) against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): object ids and depth bit-exact; hit position/distance bit-exact;
+RGB within 1/255 in raytracing mode; photon maps compared record by record under a fixed seed and
+photon-mapped frames within a stated MAE.  Where device libm (ocml) and glibc differ in the last
+ulp (atan2f/acosf feed sphere UVs, powf feeds the specular term) the affected quantities get the
+tolerance written next to the assert.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import scene_kit as kit
+
+rrt = ob.rrt
+abi = rrt._abi
+pytestmark = pytest.mark.gpu
+
+REFERENCE_SCENES = ["quadratics", "reflection_refraction", "textures", "scene", "pm_diffuse", "pm_caustics", "scene2", "c2_quadric_csg_fresnel"]
+# scenes whose RGB depends on sphere UVs (atan2f / acosf -> texel index): a one-ulp libm difference can pick the
+# neighbouring texel in a handful of pixels
+UV_SENSITIVE = {"textures", "scene", "pm_diffuse"}
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def load_pair(repo, name, mode=abi.MODE_SCENE, params=None):
+    path = os.path.join(repo, "assets/scenes", name + ".txt")
+    cpu, cam = ob.OracleScene.load(path, params=params, mode_override=mode)
+    gpu, _ = rrt.Scene.load(path, params=params, mode_override=mode)
+    return cpu, gpu, cam
+
+
+@pytest.mark.parametrize("name", REFERENCE_SCENES)
+def test_frames_match_oracle_in_raytracing_mode(repo, name):
+    cpu, gpu, cam = load_pair(repo, name)
+    cam.width, cam.height = 320, 200  # non-square, not a multiple of the block size
+    gpu.pre_render(1)
+    rgb_g, depth_g, id_g = gpu.render(cam)
+    rgb_c, depth_c, id_c = cpu.render(cam)
+    assert np.array_equal(id_g, id_c)                      # bit-exact primary-hit object ids
+    assert np.array_equal(bits(depth_g), bits(depth_c))    # bit-exact depth buffer
+    dq = np.abs(rrt.quantise(rgb_g).astype(int) - ob.quantise(rgb_c).astype(int))
+    if name in UV_SENSITIVE:
+        assert (dq > 1).mean() < 1e-4, "more than 0.01%% of channels beyond 1/255 (max %d)" % dq.max()
+    else:
+        assert dq.max() <= 1
+    # identical work: the same number of secondary and shadow rays were traced
+    sg, sc = gpu.stats(), cpu.stats()
+    for k in ("rays_primary", "rays_secondary", "rays_shadow"):
+        if name in UV_SENSITIVE:  # a normal-map texel picked one ulp apart can flip a `ldir . n > 0` test
+            assert abs(sg[k] - sc[k]) <= 1e-4 * sc[k], k
+        else:
+            assert sg[k] == sc[k], k
+
+
+@pytest.mark.parametrize("name", REFERENCE_SCENES)
+def test_trace_and_shadowtrace_match_oracle_on_random_rays(repo, name):
+    cpu, gpu, cam = load_pair(repo, name)
+    gpu.pre_render(1)
+    towards = (0.0, 2.0, 5.0) if name not in ("quadratics", "reflection_refraction", "c2_quadric_csg_fresnel") else (0.0, 0.0, 1.0)
+    o, d = kit.random_rays(20000, 42, origin_scale=6.0, towards=towards, spread=5.0)
+    g, c = gpu.trace(o, d), cpu.trace(o, d)
+    assert (c["object_id"] != abi.MISS).mean() > 0.15
+    for k in ("object_id", "prim_id", "distance", "position"):
+        assert np.array_equal(bits(g[k]), bits(c[k])), k
+    hit = c["object_id"] != abi.MISS
+    # uv of sphere hits goes through atan2f/acosf (ocml vs glibc: <= 2 ulp); normals through normal maps picked by uv
+    assert np.allclose(g["uv"][hit], c["uv"][hit], rtol=0, atol=1e-6, equal_nan=True)
+    same_n = (bits(g["normal"]) == bits(c["normal"])).all(axis=1)
+    assert same_n[hit].mean() > 0.999
+    assert np.abs(g["normal"] - c["normal"]).max() < 0.2
+    limits = np.random.default_rng(1).random(o.shape[0]).astype(np.float32) * 12.0
+    assert np.array_equal(gpu.shadowtrace(o, d, limits), cpu.shadowtrace(o, d, limits))
+
+
+def test_primitives_known_answers_on_gpu():
+    """The known answers of SURVEY.md §8c straight through the C ABI (no oracle involved)."""
+    s = rrt.Scene()
+    m = kit.monochrome(s)
+    s.add_object(kit.sphere(s, (0, 0, 0), 1.0, m))
+    s.add_object(kit.cuboid(s, (10, 0, 0), (1, 1, 1), m))
+    s.add_object(kit.quadric(s, (1, 0, 0, 0, 1, 0, 0, 1, 0, -1), m))  # unit sphere as a quadric, hidden behind object 0 on ties
+    s.add_object(kit.plane(s, (0, -50, 0), (0, 0, 1), (0, 1, 0), m))
+    s.pre_render(1)
+    r = s.trace([(0, 0, -5), (10.5, 0.5, -2), (0, 3, 0), (30, 3, 0)], [(0, 0, 1), (0, 0, 1), (0, 1, 0), (0, -1, 0)])
+    assert list(r["object_id"]) == [0, 1, abi.MISS, 3]       # strict `<`: the first object wins the sphere/quadric tie
+    assert list(r["distance"]) == [4.0, 2.0, 0.0, 53.0]
+    assert np.array_equal(r["normal"][0], [0, 0, -1]) and np.array_equal(r["normal"][1], [0, 0, -1]) and np.array_equal(r["normal"][3], [0, 1, 0])
+    assert r["uv"][0][0] == pytest.approx(1.0, abs=1e-6) and r["uv"][0][1] == pytest.approx(0.5, abs=1e-6)
+
+
+@pytest.mark.parametrize("mode", [abi.CSG_UNION, abi.CSG_INTERSECTION, abi.CSG_DIFFERENCE])
+def test_csg_interval_lists_match_oracle(mode):
+    def build(s):
+        m1, m2, m3 = kit.monochrome(s, (1, 0, 0)), kit.monochrome(s, (0, 1, 0)), kit.monochrome(s, (0, 0, 1))
+        a = kit.csg(s, mode, kit.sphere(s, (0, 0, 0), 1.0, m1), kit.cuboid(s, (-0.3, -0.3, -2), (0.9, 0.9, 2.5), m2))
+        b = kit.csg(s, abi.CSG_DIFFERENCE, a, kit.quadric(s, (4, 0, 0, 0, 0, 0, 0, 4, 0, -1), m3))
+        s.add_object(b)
+        s.add_object(kit.csg(s, mode, kit.plane(s, (0, -1.5, 0), (0, 0, 1), (0, 1, 0), m2), kit.sphere(s, (3, -1.5, 0), 1.0, m1)))
+        kit.light(s, abi.LIGHT_POINT, position=(2, 4, -3), colour=(1, 1, 1))
+
+    cpu, gpu = ob.OracleScene(), rrt.Scene()
+    build(cpu)
+    build(gpu)
+    gpu.pre_render(1)
+    o, d = kit.random_rays(30000, 7, origin_scale=4.0, towards=(0.5, -0.3, 0.0), spread=2.5)
+    g, c = gpu.trace(o, d), cpu.trace(o, d)
+    for k in ("object_id", "prim_id", "distance", "position", "normal"):
+        assert np.array_equal(bits(g[k]), bits(c[k])), k
+    rg, rc = gpu.raytrace(o[:4000], d[:4000]), cpu.raytrace(o[:4000], d[:4000])
+    assert np.array_equal(rg[2], rc[2]) and np.array_equal(bits(rg[1]), bits(rc[1]))
+    assert np.abs(rrt.quantise(rg[0]).astype(int) - ob.quantise(rc[0]).astype(int)).max() <= 1
+
+
+def test_hitvec_overflow_is_reported_from_the_device():
+    s = rrt.Scene()
+    m = kit.monochrome(s)
+    h = kit.sphere(s, (0, 0, 0), 1.0, m)
+    for k in range(1, 4):
+        h = kit.csg(s, abi.CSG_UNION, h, kit.sphere(s, (0, 0, 3.0 * k), 1.0, m))
+    s.add_object(h)
+    s.pre_render(1)
+    with pytest.raises(rrt.RrtError) as e:
+        s.trace([(0, 0, -5)], [(0, 0, 1)])
+    assert e.value.code == abi.ERR_OVERFLOW  # core/hit.rs:70-73 panics here
+    assert s.trace([(5, 5, -5)], [(0, 0, 1)])["object_id"][0] == abi.MISS
+
+
+# ---- meshes: BVH traversal vs the reference's brute-force loop ---------------------------------------------------
+def adversarial_rays(pos, n, seed):
+    """Random rays plus the cases a BVH gets wrong first: axis-parallel rays through vertices, origins on box
+    planes, grazing rays along edges, far-away origins (cancellation in o + d*t)."""
+    rng = np.random.default_rng(seed)
+    v = pos.reshape(-1, 3)
+    lo, hi = v.min(0), v.max(0)
+    c, ext = (lo + hi) / 2, (hi - lo).max()
+    o, d = kit.random_rays(n, seed, origin_scale=ext * 1.5, towards=c, spread=ext * 0.6)
+    o += c.astype(np.float32)
+    k = n // 8
+    pick = v[rng.integers(0, len(v), k)]
+    axis = rng.integers(0, 3, k)
+    o[:k] = pick
+    o[np.arange(k), axis] = (lo - ext)[axis]
+    d[:k] = np.eye(3, dtype=np.float32)[axis]            # axis-parallel through a vertex
+    e0 = v[rng.integers(0, len(v) // 3, k) * 3]
+    e1 = v[rng.integers(0, len(v) // 3, k) * 3 + 1]
+    dd = (e1 - e0) + (rng.random((k, 3)) - 0.5) * 1e-3 * ext
+    nn = np.linalg.norm(dd, axis=1, keepdims=True)
+    ok = nn[:, 0] > 0
+    d[k:2 * k][ok] = (dd / np.where(nn > 0, nn, 1))[ok]
+    o[k:2 * k] = e0 - d[k:2 * k] * ext                      # grazing along an edge
+    far = slice(2 * k, 3 * k)
+    o[far] = c + (o[far] - c) * 400.0                      # origins hundreds of extents away
+    t = c + (rng.random((k, 3)) - 0.5) * ext * 0.8
+    dv = t - o[far]
+    d[far] = dv / np.linalg.norm(dv, axis=1, keepdims=True)
+    return np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32)
+
+
+def mesh_pair(pos, nrm, smooth):
+    cpu, gpu = ob.OracleScene(), rrt.Scene()
+    for s in (cpu, gpu):
+        s.add_object(kit.mesh(s, pos, nrm, kit.falsecolour(s), smooth))
+    gpu.pre_render(1)
+    return cpu, gpu
+
+
+def check_mesh(cpu, gpu, o, d):
+    g, c = gpu.trace(o, d), cpu.trace(o, d)
+    assert (c["object_id"] != abi.MISS).sum() > 50
+    for k in ("object_id", "prim_id", "distance", "position", "normal"):
+        assert np.array_equal(bits(g[k]), bits(c[k])), k
+    lim = np.abs(o).max(axis=1).astype(np.float32)
+    assert np.array_equal(gpu.shadowtrace(o, d, lim), cpu.shadowtrace(o, d, lim))
+
+
+def load_teapot(repo, name="teapot.obj"):
+    import test_host_side
+
+    return test_host_side.python_obj_loader(os.path.join(repo, "assets/models", name))
+
+
+def test_bvh_equals_brute_force_teapot(repo):
+    pos, nrm = load_teapot(repo)
+    cpu, gpu = mesh_pair(pos, nrm, True)
+    o, d = adversarial_rays(pos, 24000, 3)
+    check_mesh(cpu, gpu, o, d)
+    assert gpu.stats()["bvh_tris_tested"] < 0.05 * o.shape[0] * pos.shape[0]  # the BVH actually prunes
+
+
+def test_bvh_equals_brute_force_triangle_soup():
+    rng = np.random.default_rng(5)
+    n = 30000
+    centre = (rng.random((n, 1, 3)) - 0.5) * 20
+    pos = (centre + (rng.random((n, 3, 3)) - 0.5) * rng.choice([0.05, 0.5, 3.0], (n, 1, 1))).astype(np.float32)
+    pos[:50] = pos[50:100]            # exact duplicates: ties must go to the lowest index
+    pos[100:110, 2] = pos[100:110, 1]  # degenerate (zero-area) triangles never hit
+    cpu, gpu = mesh_pair(pos, None, False)
+    o, d = adversarial_rays(pos, 6000, 8)
+    check_mesh(cpu, gpu, o, d)
+
+
+def test_bvh_tiny_meshes():
+    for n in (1, 2, 4, 5):
+        pos = np.array([[[0, 0, k], [1, 0, k], [0, 1, k]] for k in range(n)], np.float32)
+        cpu, gpu = mesh_pair(pos, None, False)
+        o = np.array([(0.2, 0.2, -3), (0.2, 0.2, n + 3), (5, 5, -3), (0.2, 0.2, 0.5)], np.float32)
+        d = np.array([(0, 0, 1), (0, 0, -1), (0, 0, 1), (0, 0, 1)], np.float32)
+        g, c = gpu.trace(o, d), cpu.trace(o, d)
+        for k in ("object_id", "prim_id", "distance"):
+            assert np.array_equal(bits(g[k]), bits(c[k])), (n, k)
+
+
+def test_scene2_transformed_teapot_and_normals(repo):
+    # Model rules of scene_file.rs:361-402: rotate_teapot, then scale + translate in one matrix, smooth normals
+    cpu, gpu, cam = load_pair(repo, "scene2")
+    gpu.pre_render(1)
+    rng = np.random.default_rng(12)
+    centre = np.array([1.5, 4.8, 5.1], np.float32)          # the teapot after scale 0.04 + translate
+    off = rng.normal(size=(20000, 3)).astype(np.float32)
+    o = centre + 2.0 * off / np.linalg.norm(off, axis=1, keepdims=True)
+    t = centre + (rng.random((20000, 3)).astype(np.float32) - 0.5) * np.array([1.4, 0.7, 1.0], np.float32)
+    d = t - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o, d = np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32)
+    g, c = gpu.trace(o, d), cpu.trace(o, d)
+    assert (c["object_id"] == 8).sum() > 2000
+    for k in ("object_id", "prim_id", "distance", "position", "normal"):
+        assert np.array_equal(bits(g[k]), bits(c[k])), k
+
+
+# ---- full-size, size-independent properties ------------------------------------------------------------------------
+def test_full_size_frame_properties(repo):
+    """BASELINE configs[1] at its full 1920x1080: the oracle would take a while, so check what does not need it:
+    band independence (the multi-GPU shard unit), chunk independence, run-to-run determinism, the batched
+    raytrace entry, and the oracle on a sample of rows."""
+    path = os.path.join(repo, "assets/scenes/c2_quadric_csg_fresnel.txt")
+    gpu, cam = rrt.Scene.load(path)
+    gpu.pre_render(1)
+    rgb, depth, ids = gpu.render(cam)
+    assert rgb.shape == (1080, 1920, 3)
+    st_full = gpu.stats()
+    again = gpu.render(cam)
+    assert all(np.array_equal(bits(a), bits(b)) for a, b in zip((rgb, depth, ids), again))
+    parts = [gpu.render(cam, y0, y1) for (y0, y1) in ((0, 135), (135, 700), (700, 1080))]
+    assert np.array_equal(bits(np.concatenate([p[0] for p in parts])), bits(rgb))
+    assert np.array_equal(bits(np.concatenate([p[1] for p in parts])), bits(depth))
+    small = rrt.Scene.load(path, params=rrt.default_params(chunk_pixels=100_003))[0]
+    small.pre_render(1)
+    chunked = small.render(cam)
+    assert all(np.array_equal(bits(a), bits(b)) for a, b in zip((rgb, depth, ids), chunked))
+    assert small.stats()["rays_secondary"] == st_full["rays_secondary"] and small.stats()["rays_shadow"] == st_full["rays_shadow"]
+    rows = [7, 333, 540, 901, 1079]
+    cpu, _ = ob.OracleScene.load(path)
+    for y in rows:
+        rc, dc, ic = cpu.render(cam, y, y + 1)
+        assert np.array_equal(ic[0], ids[y]) and np.array_equal(bits(dc[0]), bits(depth[y]))
+        assert np.abs(ob.quantise(rc[0]).astype(int) - rrt.quantise(rgb[y]).astype(int)).max() <= 1
+    o = np.zeros((1920, 3), np.float32)
+    d = np.zeros((1920, 3), np.float32)
+    for x in range(1920):
+        o[x], d[x] = rrt.camera_ray(cam, x, 540)
+    r_rgb, r_depth, r_ids = gpu.raytrace(o, d)
+    assert np.array_equal(r_ids, ids[540]) and np.array_equal(bits(r_depth), bits(depth[540])) and np.array_equal(bits(r_rgb), bits(rgb[540]))
+
+
+def test_render_rejects_bad_input(repo):
+    gpu, cam = rrt.Scene.load(os.path.join(repo, "assets/scenes/quadratics.txt"))
+    with pytest.raises(rrt.RrtError) as e:
+        gpu.render(cam)
+    assert e.value.code == abi.ERR_STATE  # render before pre_render
+    gpu.pre_render(1)
+    with pytest.raises(rrt.RrtError):
+        gpu.render(cam, 10, 5000)
+    rgb, depth, ids = gpu.render(cam, 5, 5)  # empty band
+    assert rgb.shape == (0, 1024, 3)
+    r = gpu.trace(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert r["object_id"].shape == (0,)
+    empty = rrt.Scene()
+    empty.pre_render(1)
+    cam.width = cam.height = 8
+    rgb, depth, ids = empty.render(cam)  # a scene with no objects: scene.rs:85-90
+    assert (ids == abi.MISS).all() and not rgb.any() and not depth.any()
