@@ -1,0 +1,206 @@
+"""Extra single-GPU legs of bench.py: the other two one-GPU configurations of BASELINE.json.
+
+mesh    configs[3]: a 1 M-triangle mesh (13 x 13 grid of assets/models/teapot.obj = 1,068,080 triangles,
+        generated here deterministically — the reference ships no mesh of that size) at 3840 x 2160,
+        Monochrome material, one point light: BVH traversal for primary and shadow rays.
+photon  configs[2]: assets/scenes/scene2.txt in photon mode, 1 M photons + 10 k caustic, seed 1, 1024^2:
+        emission/bounce pass, index build, gather render.
+"""
+import ctypes as C
+import math
+import os
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def load_obj_triangles(path):
+    """v / vn / f (3 or 4 corners, fan) -> corner positions and normals, as polymesh_object.rs:57-194."""
+    verts, normals, pos, nrm = [], [], [], []
+    for line in open(path):
+        w = line.split()
+        if not w:
+            continue
+        if w[0] == "v":
+            verts.append([float(x) for x in w[1:4]])
+        elif w[0] == "vn":
+            normals.append([float(x) for x in w[1:4]])
+        elif w[0] == "f":
+            idx = [(int(c.split("/")[0]) - 1, int(c.split("/")[2]) - 1) for c in w[1:]]
+            for t in [(0, 1, 2)] + ([(0, 2, 3)] if len(idx) == 4 else []):
+                for c in t:
+                    pos.append(verts[idx[c][0]])
+                    nrm.append(normals[idx[c][1]])
+    return np.array(pos, np.float32).reshape(-1, 3, 3), np.array(nrm, np.float32).reshape(-1, 3, 3)
+
+
+def teapot_grid(nx=13, nz=13, spacing=34.0):
+    pos, nrm = load_obj_triangles(os.path.join(REPO, "assets/models/teapot.obj"))
+    # the OBJ is z-up: rotate to y-up like scene_file.rs:372-381 (x, z, -y)
+    rot = lambda a: np.stack([a[..., 0], a[..., 2], -a[..., 1]], axis=-1)
+    pos, nrm = rot(pos), rot(nrm)
+    P, N = [], []
+    for j in range(nz):
+        for i in range(nx):
+            off = np.array([(i - (nx - 1) / 2) * spacing, 0.0, (j - (nz - 1) / 2) * spacing], np.float32)
+            P.append(pos + off)
+            N.append(nrm)
+    return np.ascontiguousarray(np.concatenate(P), np.float32), np.ascontiguousarray(np.concatenate(N), np.float32)
+
+
+def build_mesh_scene(rrt, smooth=True):
+    abi = rrt._abi
+    pos, nrm = teapot_grid()
+    s = rrt.Scene()
+    m = abi.MaterialDesc()
+    m.kind = abi.MAT_MONOCHROME
+    m.colour[:] = (0.8, 0.6, 0.2)
+    m.ambient, m.shininess = 0.1, 50.0
+    m.diffuse_tex = m.normal_tex = -1
+    mat = s.add_material(m)
+    d = abi.ObjectDesc()
+    d.kind = abi.OBJ_MESH
+    d.material = mat
+    d.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
+    d.normals = nrm.ctypes.data_as(C.POINTER(C.c_float))
+    d.n_triangles = pos.shape[0]
+    d.smooth = 1 if smooth else 0
+    s.add_object(s.object_define(d))
+    f = abi.MaterialDesc()
+    f.kind = abi.MAT_MONOCHROME
+    f.colour[:] = (0.3, 0.5, 0.3)
+    f.ambient, f.shininess = 0.1, 100.0
+    f.diffuse_tex = f.normal_tex = -1
+    floor = abi.ObjectDesc()
+    floor.kind = abi.OBJ_PLANE
+    floor.material = s.add_material(f)
+    floor.v[:9] = (0, 0, 0, 0, 0, 1, 0, 1, 0)
+    s.add_object(s.object_define(floor))
+    l = abi.LightDesc()
+    l.kind = abi.LIGHT_POINT
+    l.position[:] = (0.0, 400.0, -300.0)
+    l.colour[:] = (1.2, 1.2, 1.2)
+    s.add_light(l)
+    cam = rrt.make_camera(3840, 2160, math.radians(40.0), (0.0, 260.0, -420.0), (0.0, 0.55, 1.0))  # file-space lookat: +y looks down (full_camera.rs:31-34)
+    return s, cam, pos.shape[0]
+
+
+def run_mesh(rrt, torch, steps=5):
+    t0 = time.perf_counter()
+    scene, cam, ntri = build_mesh_scene(rrt)
+    t_build_host = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    scene.pre_render(1)
+    t_pre = time.perf_counter() - t0
+    W, H = cam.width, cam.height
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), stream)
+    torch.cuda.synchronize()
+    rays = kernel_ms = flops = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), stream)
+        st = scene.stats()
+        rays += st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+        kernel_ms += st["ms_trace_kernels"]
+        flops += st["flops_algorithmic"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    achieved = flops / (kernel_ms * 1e-3) / 1e12
+    return {
+        "workload": "BASELINE configs[3]: %d-triangle mesh (13x13 teapot.obj grid) + floor, 3840x2160, 1 point light" % ntri,
+        "value": rays / dt / 1e6,
+        "unit": "Mrays/s",
+        "ms_per_frame": dt / steps * 1e3,
+        "rays_per_frame": rays // steps,
+        "hit_fraction": float((ids >= 0).float().mean().item()),
+        "bvh_nodes_per_ray": st["bvh_nodes_visited"] / (st["rays_primary"] + st["rays_shadow"]),
+        "bvh_tris_per_ray": st["bvh_tris_tested"] / (st["rays_primary"] + st["rays_shadow"]),
+        "host_seconds": {"mesh_generation": t_build_host, "pre_render_incl_bvh_build": t_pre},
+        "roofline": {"kernel": "k_trace_shade", "bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_TFLOPS, "kernel_ms_per_frame": kernel_ms / steps},
+    }
+
+
+def run_photon(rrt, torch, photons=1_000_000, steps=3):
+    params = rrt.default_params(photons_per_light=photons, caustic_photons_per_light=10_000)
+    scene, cam = rrt.Scene.load(os.path.join(REPO, "assets/scenes/scene2.txt"), params=params)
+    scene.pre_render(1)  # warm-up (allocations, code objects)
+    W, H = cam.width, cam.height
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), stream)
+    torch.cuda.synchronize()
+    t_shoot = t_build = t_render = 0.0
+    gathered = cand = queries = stored = 0
+    kernel_ms = 0.0
+    for i in range(steps):
+        t0 = time.perf_counter()
+        scene.pre_render(1 + i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        st = scene.stats()
+        t_shoot += st["ms_photon_shoot"] * 1e-3
+        t_build += st["ms_photon_build"] * 1e-3
+        t_render += t2 - t1
+        kernel_ms += st["ms_trace_kernels"]
+        gathered += st["photons_gathered"]
+        cand += st["gather_candidates"]
+        queries += st["gather_queries"]
+        stored = st["photons_stored_regular"] + st["photons_stored_caustic"]
+    emitted = (photons + 10_000) * steps
+    # algorithmic bytes of the gather: 36 B per photon inside a query cube + 8 B per touched cell
+    gather_bytes = 36.0 * gathered + 8.0 * 8 * queries
+    gbs = gather_bytes / (kernel_ms * 1e-3) / 1e9
+    return {
+        "workload": "BASELINE configs[2]: scene2 photon mode, %d + 10000 photons, seed 1.., 1024x1024" % photons,
+        "mphotons_per_s_emitted_trace_pass": emitted / t_shoot / 1e6,
+        "mphotons_per_s_gathered_render_pass": gathered / t_render / 1e6,
+        "ms": {"photon_shoot": t_shoot / steps * 1e3, "index_build": t_build / steps * 1e3, "render": t_render / steps * 1e3,
+               "render_kernels": kernel_ms / steps},
+        "records_stored": stored,
+        "gathered_per_frame": gathered // steps,
+        "candidates_read_per_frame": cand // steps,
+        "roofline": {"kernel": "k_trace_shade (photon mode: trace + gather)", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": gbs / PEAK_HBM_GBS, "traffic": None},
+    }
+
+
+def run(rrt, torch):
+    out = {}
+    for name, fn in (("mesh_1m", run_mesh), ("photon_1m", run_photon)):
+        try:
+            out[name] = fn(rrt, torch)
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+    return out
+
+
+if __name__ == "__main__":
+    import importlib
+    import json
+    import sys
+
+    import torch
+
+    sys.path.insert(0, REPO)
+    rrt = importlib.import_module("rust-raytracer_amd")
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    res = {}
+    if which in ("all", "mesh"):
+        res["mesh_1m"] = run_mesh(rrt, torch)
+    if which in ("all", "photon"):
+        res["photon_1m"] = run_photon(rrt, torch)
+    print(json.dumps(res, indent=1))
