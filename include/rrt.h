@@ -52,7 +52,7 @@ typedef struct rrt_params {
                                            this build stops a path after this many landings (64)    */
     uint32_t max_vueon_depth;           /* reference: unbounded (photon_scene.rs:329-352); deeper
                                            vueons return black here (default 12)                    */
-    uint32_t chunk_pixels;              /* pixels per wavefront-queue chunk (0 = default 1<<20)     */
+    uint32_t chunk_pixels;              /* pixels per wavefront-queue chunk (0 = default 1<<22)     */
     uint32_t reserved[9];
 } rrt_params;
 

@@ -19,7 +19,7 @@ from . import _abi
 from ._abi import *  # noqa: F401,F403
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librrt.so")
+LIB_PATH = os.environ.get("RRT_LIB", os.path.join(_HERE, "librrt.so"))  # RRT_LIB: kernel-variant experiments only
 REPO_ROOT = os.path.dirname(_HERE)
 
 

@@ -62,7 +62,13 @@ __device__ __forceinline__ void camera_ray(const DevCamera &C, uint32_t x, uint3
     o = C.position;
 }
 
-__global__ __launch_bounds__(RRT_BLOCK) void k_trace_shade(TraceArgs A) {
+#ifndef RRT_MIN_WAVES
+#define RRT_MIN_WAVES 1
+#endif
+// MODE is a template parameter so that the raytracing-mode instance does not carry the registers of the photon
+// gather and vice versa (occupancy is VGPR-limited here).
+template <int MODE>
+__global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
     const DevScene &S = A.S;
     Lds lds = make_lds(A.lds_slots);
     uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_trace_shade(TraceArgs A) {
             float kr = 0.0f;
             A.cur.object_id[i] = tr.object;
             A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, tr.t);  // depth = hit.distance (scene.rs:124-127)
-            if (A.mode == RRT_MODE_SCENE) {
+            if (MODE == RRT_MODE_SCENE) {
                 f3 once = material_once_pre(S, M, h, cnt);
                 float wr = 0.0f, wt = 0.0f;
                 if (M.global_part >= 0) {  // GlobalMaterial::compute_once, global_material.rs:71-98
@@ -327,7 +333,10 @@ static inline uint32_t blocks_for(uint32_t n) { return (n + RRT_BLOCK - 1) / RRT
 
 void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream) {
     if (a.count == 0) return;
-    hipLaunchKernelGGL(k_trace_shade, dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes, stream, a);
+    if (a.mode == RRT_MODE_SCENE)
+        hipLaunchKernelGGL(k_trace_shade<RRT_MODE_SCENE>, dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes, stream, a);
+    else
+        hipLaunchKernelGGL(k_trace_shade<RRT_MODE_PHOTON>, dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes, stream, a);
 }
 void launch_combine(const TraceArgs &a, hipStream_t stream) {
     if (a.count == 0) return;

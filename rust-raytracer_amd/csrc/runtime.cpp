@@ -397,7 +397,7 @@ int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixe
     const uint32_t n_levels = D.reflective ? depth_cap + 1 : 1;
     if (n_levels + 2 > 60) return fail(RRT_ERR_LIMIT, "recursion depth above 57");
     if (s->levels.size() < n_levels + 1) s->levels.resize(n_levels + 1);
-    uint32_t chunk = s->params.chunk_pixels ? s->params.chunk_pixels : (1u << 20);
+    uint32_t chunk = s->params.chunk_pixels ? s->params.chunk_pixels : (1u << 22);
     int rc;
     uint32_t *err_dev = s->counters.p + 63;
     RRT_HIP(hipMemsetAsync(s->counters.p, 0, 64 * sizeof(uint32_t), stream));
