@@ -26,27 +26,31 @@ enum Op : uint32_t {
     OP_CSG_INTERSECTION = 6,
     OP_CSG_DIFFERENCE = 7
 };
-struct Instr {
-    uint32_t op;
-    uint32_t index;  // into the array of its primitive type
+// One 64-byte record per instruction, primitive parameters inline: the trace loop streams through ONE array with
+// wave-uniform sequential addresses (scalar loads, no dependent index -> data chains).
+//   plane   p = normal.xyz, d                       aux = plane_cold index
+//   sphere  p = centre.xyz, radius
+//   cuboid  p = lo.xyz, hi.xyz (with the +-1e-4 slack of cuboid_object.rs:107-112), d of its 6 planes
+//                                                   aux = plane_cold index of the first of its 6 planes
+//   quadric p = a b c d e f g h i j
+//   mesh                                            aux = mesh index
+struct ProgRec {
+    uint32_t op;      // Op in bits 0..7 | PF_* flags
+    uint32_t object;  // index into Environment::objects()
+    int32_t material;
+    uint32_t aux;
+    float p[12];
 };
-struct ObjectRange {
-    uint32_t first, count;  // instruction range
-};
+enum ProgFlags : uint32_t { PF_FIRST = 0x100, PF_LAST = 0x200, PF_CSG = 0x400 };
 
-// Plane::intersect needs only (normal, d): plane_object.rs:57-58
+// winner-only plane data (uv frame, tangent frame); Plane::intersect itself needs only (normal, d)
 struct PlaneCold {
+    f3 normal;
+    float d;
     f3 centre;
     f3 u_unit, v_unit;     // plane_object.rs:96-97, ray independent
     f3 tan_t, tan_b, tan_n;  // columns of to_tangent_space(right, normal), vector.rs:133-142
     int32_t material;
-};
-struct CuboidHot {
-    float4 lo;  // corner - 1e-4 per axis (cuboid_object.rs:107-112); w = first plane index as int bits
-    float4 hi;  // (corner + size) + 1e-4
-};
-struct QuadricHot {
-    float4 abcd, efgh, ij_mat;  // ij_mat = (i, j, material bits, 0)
 };
 // Triangle as the traversal reads it: 64 B, one cache line pair per two triangles
 struct TriHot {
@@ -103,18 +107,12 @@ struct DevLight {
 };
 
 struct DevScene {
-    const Instr *instrs;
-    const ObjectRange *objects;
+    const ProgRec *prog;
+    uint32_t n_prog;
     uint32_t n_objects;
     uint32_t n_lights;
-    uint32_t max_program;  // longest object program
     uint32_t has_csg;
-    const float4 *plane_hot;  // (normal.xyz, d)
     const PlaneCold *plane_cold;
-    const float4 *sphere_hot;  // (centre.xyz, radius)
-    const int32_t *sphere_mat;
-    const CuboidHot *cuboid_hot;
-    const QuadricHot *quadric_hot;
     const MeshInfo *meshes;
     const TriHot *tris;        // BVH order
     const uint32_t *tri_index; // BVH order -> original triangle index

@@ -90,10 +90,10 @@ __device__ __forceinline__ bool sphere_hits(float4 cr, f3 o, f3 d, float &t0, fl
 }
 
 // Quadratic::intersect (quadratic_object.rs:43-89)
-__device__ __forceinline__ bool quadric_hits(const QuadricHot &Q, f3 P, f3 D, float &t0, float &t1) {
-    float a = Q.abcd.x, b = Q.abcd.y, c = Q.abcd.z, d = Q.abcd.w;
-    float e = Q.efgh.x, f = Q.efgh.y, g = Q.efgh.z, h = Q.efgh.w;
-    float i = Q.ij_mat.x, j = Q.ij_mat.y;
+__device__ __forceinline__ bool quadric_hits(const float *q, f3 P, f3 D, float &t0, float &t1) {
+    float a = q[0], b = q[1], c = q[2], d = q[3];
+    float e = q[4], f = q[5], g = q[6], h = q[7];
+    float i = q[8], j = q[9];
     float Aq = a * (D.x * D.x) + 2.0f * b * D.x * D.y + 2.0f * c * D.x * D.z + e * (D.y * D.y) + 2.0f * f * D.y * D.z +
                h * (D.z * D.z);
     float Bq = 2.0f * (a * P.x * D.x + b * (P.x * D.y + P.y * D.x) + c * (P.x * D.z + D.x * P.z) + d * D.x + e * P.y * D.y +
@@ -119,23 +119,23 @@ __device__ __forceinline__ bool quadric_hits(const QuadricHot &Q, f3 P, f3 D, fl
 // Cuboid::intersect (cuboid_object.rs:94-148): six half-space planes; the entering candidate with
 // the LARGEST distance and the exiting candidate with the SMALLEST distance survive (later planes
 // replace on ties).  sub = plane * 2 + position of the hit in that plane's list.
-__device__ __forceinline__ void cuboid_hits(const DevScene &S, const CuboidHot &C, f3 o, f3 d, bool &have_first, float &t_first,
-                                            uint32_t &sub_first, bool &have_back, float &t_back, uint32_t &sub_back) {
+__device__ __forceinline__ void cuboid_hits(const ProgRec &C, f3 o, f3 d, bool &have_first, float &t_first, uint32_t &sub_first,
+                                            bool &have_back, float &t_back, uint32_t &sub_back) {
     have_first = have_back = false;
     t_first = t_back = 0.0f;
     sub_first = sub_back = 0;
-    uint32_t p0 = __float_as_uint(C.lo.w);
+    // plane order = CuboidPlanes::iter (cuboid_object.rs:27-37): left, right, up, down, front, back
+    const f3 normals[6] = {{-1.0f, 0.0f, 0.0f}, {1.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f}, {0.0f, -1.0f, 0.0f}, {0.0f, 0.0f, -1.0f}, {0.0f, 0.0f, 1.0f}};
 #pragma unroll
     for (uint32_t p = 0; p < 6; p++) {
-        float4 nd = S.plane_hot[p0 + p];
-        f3 n = mk3(nd.x, nd.y, nd.z);
-        float U = dot3(n, o) + nd.w;
+        f3 n = normals[p];
+        float U = dot3(n, o) + C.p[6 + p];
         float V = dot3(n, d);
         if (V == 0.0f) continue;  // both hits infinite: skipped at cuboid_object.rs:120-122
         float t = U / -V;
         bool entering = !(V > 0.0f);
         f3 hp = o + d * t;
-        bool inside = hp.x >= C.lo.x && hp.x <= C.hi.x && hp.y >= C.lo.y && hp.y <= C.hi.y && hp.z >= C.lo.z && hp.z <= C.hi.z;
+        bool inside = hp.x >= C.p[0] && hp.x <= C.p[3] && hp.y >= C.p[1] && hp.y <= C.p[4] && hp.z >= C.p[2] && hp.z <= C.p[5];
         if (!inside) continue;
         if (t < 0.0f) continue;
         if (isinf(t)) continue;
@@ -329,43 +329,46 @@ __device__ __forceinline__ void csg_merge(uint32_t mode, Lds &lds, uint32_t sl, 
     }
 }
 
+__device__ __forceinline__ float4 rec4(const ProgRec &r) { return make_float4(r.p[0], r.p[1], r.p[2], r.p[3]); }
+
 // Leaf of a CSG program: write the primitive's hit list into LDS slot `slot`, return its length.
-__device__ __forceinline__ uint32_t leaf_list(const DevScene &S, Instr in, uint32_t local, f3 o, f3 d, Lds &lds, uint32_t slot) {
-    switch (in.op) {
+// `k` = index of the record in the program (kept in the meta word so the winner can be re-evaluated).
+__device__ __forceinline__ uint32_t leaf_list(const ProgRec &r, uint32_t k, f3 o, f3 d, Lds &lds, uint32_t slot) {
+    switch (r.op & 0xFFu) {
         case OP_PLANE: {
             float t0, t1;
             bool e0, e1;
-            if (plane_hits(S.plane_hot[in.index], o, d, t0, e0, t1, e1) == 0) return 0;
-            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(e0, local, 0);
-            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(e1, local, 1);
+            if (plane_hits(rec4(r), o, d, t0, e0, t1, e1) == 0) return 0;
+            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(e0, k, 0);
+            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(e1, k, 1);
             return 2;
         }
         case OP_SPHERE: {
             float t0, t1;
-            if (!sphere_hits(S.sphere_hot[in.index], o, d, t0, t1)) return 0;
-            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(true, local, 0);
-            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(false, local, 1);
+            if (!sphere_hits(rec4(r), o, d, t0, t1)) return 0;
+            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(true, k, 0);
+            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(false, k, 1);
             return 2;
         }
         case OP_QUADRIC: {
             float t0, t1;
-            if (!quadric_hits(S.quadric_hot[in.index], o, d, t0, t1)) return 0;
-            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(true, local, 0);
-            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(false, local, 1);
+            if (!quadric_hits(r.p, o, d, t0, t1)) return 0;
+            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(true, k, 0);
+            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(false, k, 1);
             return 2;
         }
         case OP_CUBOID: {
             bool hf, hb;
             float tf, tb;
             uint32_t sf, sb;
-            cuboid_hits(S, S.cuboid_hot[in.index], o, d, hf, tf, sf, hb, tb, sb);
+            cuboid_hits(r, o, d, hf, tf, sf, hb, tb, sb);
             uint32_t n = 0;
             if (hf) {
-                lds.t(slot, n) = tf; lds.m(slot, n) = mk_meta(true, local, sf);
+                lds.t(slot, n) = tf; lds.m(slot, n) = mk_meta(true, k, sf);
                 n++;
             }
             if (hb) {
-                lds.t(slot, n) = tb; lds.m(slot, n) = mk_meta(false, local, sb);
+                lds.t(slot, n) = tb; lds.m(slot, n) = mk_meta(false, k, sb);
                 n++;
             }
             return n;
@@ -374,21 +377,19 @@ __device__ __forceinline__ uint32_t leaf_list(const DevScene &S, Instr in, uint3
     }
 }
 
-// Run an object's CSG program; the final list ends in LDS slot `out_slot` with length `out_n`.
-// The program is wave-uniform, so the slot stack is kept in scalar registers.
-__device__ __forceinline__ void csg_eval(const DevScene &S, ObjectRange R, f3 o, f3 d, Lds &lds, Counters &cnt, uint32_t &out_slot,
-                                         uint32_t &out_n) {
-    // slot ids of the live lists, packed 4 bits each (at most 7 live lists + 1 free)
-    uint32_t stack_slots = 0, sp = 0;
-    uint32_t free_mask = 0xFFu;  // free LDS slots
-    uint32_t len_l = 0;          // per-lane lengths of live lists, packed 4 bits each by stack position
-    for (uint32_t k = 0; k < R.count; k++) {
-        Instr in = S.instrs[R.first + k];
-        if (in.op < OP_CSG_UNION) {
+// State of one CSG program evaluation.  The program is wave-uniform, so the slot stack lives in scalar registers;
+// only the list lengths are per lane.
+struct CsgState {
+    uint32_t stack_slots = 0, sp = 0;  // slot ids of the live lists, 4 bits each
+    uint32_t free_mask = 0xFFu;        // free LDS slots
+    uint32_t len_l = 0;                // per-lane lengths of the live lists, 4 bits each by stack position
+    __device__ __forceinline__ void step(const ProgRec &r, uint32_t k, f3 o, f3 d, Lds &lds, Counters &cnt) {
+        uint32_t op = r.op & 0xFFu;
+        if (op < OP_CSG_UNION) {
             uint32_t slot = __builtin_ctz(free_mask);
             free_mask &= ~(1u << slot);
-            uint32_t n = leaf_list(S, in, k, o, d, lds, slot);
-            stack_slots |= slot << (sp * 4);
+            uint32_t n = leaf_list(r, k, o, d, lds, slot);
+            stack_slots = (stack_slots & ~(15u << (sp * 4))) | (slot << (sp * 4));
             len_l = (len_l & ~(15u << (sp * 4))) | (n << (sp * 4));
             sp++;
         } else {
@@ -396,7 +397,7 @@ __device__ __forceinline__ void csg_eval(const DevScene &S, ObjectRange R, f3 o,
             uint32_t nr = (len_l >> ((sp - 1) * 4)) & 15u, nl = (len_l >> ((sp - 2) * 4)) & 15u;
             uint32_t so = __builtin_ctz(free_mask);
             uint32_t no;
-            csg_merge(in.op, lds, sl, nl, sr, nr, so, no, cnt);
+            csg_merge(op, lds, sl, nl, sr, nr, so, no, cnt);
             free_mask &= ~(1u << so);
             free_mask |= (1u << sl) | (1u << sr);
             sp -= 2;
@@ -405,39 +406,42 @@ __device__ __forceinline__ void csg_eval(const DevScene &S, ObjectRange R, f3 o,
             sp++;
         }
     }
-    out_slot = stack_slots & 15u;
-    out_n = len_l & 15u;
-}
+    __device__ __forceinline__ uint32_t out_slot() const { return stack_slots & 15u; }
+    __device__ __forceinline__ uint32_t out_len() const { return len_l & 15u; }
+    __device__ __forceinline__ void reset() {
+        stack_slots = sp = len_l = 0;
+        free_mask = 0xFFu;
+    }
+};
 
 // ---- Environment::trace (environment.rs:34-74) -----------------------------------------------------
 // First entering hit with distance >= 0 over all objects; strict `<` everywhere, so the first hit in
-// list order wins inside an object and the first object wins across objects.  `tmax_init` is
-// f32::MAX for trace; shadowtrace has its own loop below.
+// list order wins inside an object and the first object wins across objects.
 // The one entering hit a single-primitive object can produce (list position 0 of a plane, t0 of a
 // sphere / quadric, the cuboid's first_hit, the mesh's closest hit when it faces the ray), with the
 // reference's `distance < 0 -> skip` applied.  `mesh_bound`: only mesh hits below it are searched.
-__device__ __forceinline__ bool single_entering_hit(const DevScene &S, Instr in, f3 o, f3 d, float mesh_bound, Lds &lds, Counters &cnt,
-                                                    float &t_out, uint32_t &sub_out) {
+__device__ __forceinline__ bool single_entering_hit(const DevScene &S, const ProgRec &r, f3 o, f3 d, float mesh_bound, Lds &lds,
+                                                    Counters &cnt, float &t_out, uint32_t &sub_out) {
     sub_out = 0;
-    switch (in.op) {
+    switch (r.op & 0xFFu) {
         case OP_PLANE: {
             float t0, t1;
             bool e0, e1;
-            if (plane_hits(S.plane_hot[in.index], o, d, t0, e0, t1, e1) == 0) return false;
+            if (plane_hits(rec4(r), o, d, t0, e0, t1, e1) == 0) return false;
             if (t0 < 0.0f) return false;  // also the -inf entering hit of a back-facing plane
             t_out = t0;
             return true;
         }
         case OP_SPHERE: {
             float t0, t1;
-            if (!sphere_hits(S.sphere_hot[in.index], o, d, t0, t1)) return false;
+            if (!sphere_hits(rec4(r), o, d, t0, t1)) return false;
             if (t0 < 0.0f) return false;
             t_out = t0;
             return true;
         }
         case OP_QUADRIC: {
             float t0, t1;
-            if (!quadric_hits(S.quadric_hot[in.index], o, d, t0, t1)) return false;
+            if (!quadric_hits(r.p, o, d, t0, t1)) return false;
             if (t0 < 0.0f) return false;
             t_out = t0;
             return true;
@@ -446,7 +450,7 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, Instr in,
             bool hf, hb;
             float tf, tb;
             uint32_t sf, sb;
-            cuboid_hits(S, S.cuboid_hot[in.index], o, d, hf, tf, sf, hb, tb, sb);
+            cuboid_hits(r, o, d, hf, tf, sf, hb, tb, sb);
             if (!hf) return false;
             t_out = tf;
             sub_out = sf;
@@ -456,7 +460,7 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, Instr in,
             float t;
             uint32_t slot;
             bool ent;
-            if (!mesh_closest(S, S.meshes[in.index], o, d, mesh_bound, lds, cnt, t, slot, ent)) return false;
+            if (!mesh_closest(S, S.meshes[r.aux], o, d, mesh_bound, lds, cnt, t, slot, ent)) return false;
             if (!ent) return false;  // a nearer back face hides farther front faces
             t_out = t;
             sub_out = slot;
@@ -466,17 +470,8 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, Instr in,
     }
 }
 
-__device__ __forceinline__ bool object_first_hit(const DevScene &S, uint32_t obj, f3 o, f3 d, float bound, Lds &lds, Counters &cnt,
-                                                 float &t_out, uint32_t &instr_out, uint32_t &sub_out) {
-    ObjectRange R = S.objects[obj];
-    if (R.count == 1) {
-        Instr in = S.instrs[R.first];
-        instr_out = R.first;
-        if (!single_entering_hit(S, in, o, d, bound, lds, cnt, t_out, sub_out)) return false;
-        return t_out < RRT_F32_MAX;  // select_first_hit starts from f32::MAX with a strict `<`
-    }
-    uint32_t slot, n;
-    csg_eval(S, R, o, d, lds, cnt, slot, n);
+// Environment::select_first_hit (environment.rs:34-53) on the final list of a CSG object
+__device__ __forceinline__ bool csg_first_hit(Lds &lds, uint32_t slot, uint32_t n, float &t_out, uint32_t &k_out, uint32_t &sub_out) {
     bool have = false;
     float best = RRT_F32_MAX;
     for (uint32_t e = 0; e < n; e++) {
@@ -487,7 +482,7 @@ __device__ __forceinline__ bool object_first_hit(const DevScene &S, uint32_t obj
         if (t < best) {
             best = t;
             have = true;
-            instr_out = R.first + ((m >> 8) & 0xFFFFu);
+            k_out = (m >> 8) & 0xFFFFu;
             sub_out = m & 0xFFu;
         }
     }
@@ -495,19 +490,36 @@ __device__ __forceinline__ bool object_first_hit(const DevScene &S, uint32_t obj
     return have;
 }
 
+// One step of the object loop shared by trace and shadowtrace: feeds record k, and reports the object's first
+// entering hit once the object's last record has been consumed.
+__device__ __forceinline__ bool object_step(const DevScene &S, uint32_t k, const ProgRec &r, CsgState &csg, f3 o, f3 d, float bound, Lds &lds,
+                                            Counters &cnt, float &t_out, uint32_t &k_out, uint32_t &sub_out) {
+    if (!(r.op & PF_CSG)) {
+        k_out = k;
+        if (!single_entering_hit(S, r, o, d, bound, lds, cnt, t_out, sub_out)) return false;
+        return t_out < RRT_F32_MAX;  // select_first_hit starts from f32::MAX with a strict `<`
+    }
+    if (r.op & PF_FIRST) csg.reset();
+    csg.step(r, k, o, d, lds, cnt);
+    if (!(r.op & PF_LAST)) return false;
+    return csg_first_hit(lds, csg.out_slot(), csg.out_len(), t_out, k_out, sub_out);
+}
+
 __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, Counters &cnt, TraceResult &r) {
     r.object = 0xFFFFFFFFu;
     r.t = RRT_F32_MAX;
     r.instr = 0;
     r.sub = 0;
-    for (uint32_t obj = 0; obj < S.n_objects; obj++) {
+    CsgState csg;
+    for (uint32_t k = 0; k < S.n_prog; k++) {
+        const ProgRec &rec = S.prog[k];
         float t;
-        uint32_t instr, sub;
-        if (!object_first_hit(S, obj, o, d, r.t, lds, cnt, t, instr, sub)) continue;
+        uint32_t kk, sub;
+        if (!object_step(S, k, rec, csg, o, d, r.t, lds, cnt, t, kk, sub)) continue;
         if (t < r.t) {
             r.t = t;
-            r.object = obj;
-            r.instr = instr;
+            r.object = rec.object;
+            r.instr = kk;
             r.sub = sub;
         }
     }
@@ -516,12 +528,14 @@ __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, C
 // Scene::shadowtrace (scene.rs:65-79)
 __device__ __forceinline__ bool shadowtrace(const DevScene &S, f3 o, f3 d, float limit, Lds &lds, Counters &cnt) {
     cnt.shadow++;
-    for (uint32_t obj = 0; obj < S.n_objects; obj++) {
+    CsgState csg;
+    for (uint32_t k = 0; k < S.n_prog; k++) {
+        const ProgRec &rec = S.prog[k];
         float t;
-        uint32_t instr, sub;
+        uint32_t kk, sub;
         // for meshes only hits below `limit` matter: the closest hit is either below it (and found)
         // or cannot occlude
-        if (!object_first_hit(S, obj, o, d, limit, lds, cnt, t, instr, sub)) continue;
+        if (!object_step(S, k, rec, csg, o, d, limit, lds, cnt, t, kk, sub)) continue;
         if (t > 0.0000001f && t < limit) return true;
     }
     return false;
@@ -564,9 +578,8 @@ __device__ __forceinline__ bool material_normal(const DevScene &S, int32_t mater
 
 // finite plane hit attributes (plane_object.rs:74-112); `list_pos` = position in the plane's hit list
 __device__ __forceinline__ void plane_attr(const DevScene &S, uint32_t plane, uint32_t list_pos, f3 o, f3 d, float t, HitAttr &h) {
-    float4 nd = S.plane_hot[plane];
     const PlaneCold &C = S.plane_cold[plane];
-    f3 n = mk3(nd.x, nd.y, nd.z);
+    f3 n = C.normal;
     h.material = C.material;
     float V = dot3(n, d);
     bool finite_exit = (V > 0.0f) && list_pos == 1;
@@ -594,19 +607,14 @@ __device__ __forceinline__ void plane_attr(const DevScene &S, uint32_t plane, ui
 }
 
 __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t instr_index, uint32_t sub, float t, HitAttr &h) {
-    Instr in = S.instrs[instr_index];
+    const ProgRec &in = S.prog[instr_index];
     const float PI_F = 3.14159265358979323846f;
-    switch (in.op) {
-        case OP_PLANE: plane_attr(S, in.index, sub, o, d, t, h); break;
-        case OP_CUBOID: {
-            uint32_t p0 = __float_as_uint(S.cuboid_hot[in.index].lo.w);
-            plane_attr(S, p0 + (sub >> 1), sub & 1u, o, d, t, h);
-            break;
-        }
+    switch (in.op & 0xFFu) {
+        case OP_PLANE: plane_attr(S, in.aux, sub, o, d, t, h); break;
+        case OP_CUBOID: plane_attr(S, in.aux + (sub >> 1), sub & 1u, o, d, t, h); break;
         case OP_SPHERE: {  // sphere_object.rs:55-88
-            float4 cr = S.sphere_hot[in.index];
-            f3 c = mk3(cr.x, cr.y, cr.z);
-            h.material = S.sphere_mat[in.index];
+            f3 c = mk3(in.p[0], in.p[1], in.p[2]);
+            h.material = in.material;
             h.position = o + d * t;
             f3 n = norm3(h.position - c);
             if (dot3(n, d) > 0.0f) n = -n;
@@ -625,13 +633,12 @@ __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t
             break;
         }
         case OP_QUADRIC: {  // quadratic_object.rs:91-118
-            const QuadricHot &Q = S.quadric_hot[in.index];
-            h.material = (int32_t)__float_as_uint(Q.ij_mat.z);
+            const float *q = in.p;  // a b c d e f g h i j
+            h.material = in.material;
             f3 p = o + d * t;
             h.position = p;
-            f3 n = norm3(mk3(Q.abcd.x * p.x + Q.abcd.y * p.y + Q.abcd.z * p.z + Q.abcd.w,
-                             Q.abcd.y * p.x + Q.efgh.x * p.y + Q.efgh.y * p.z + Q.efgh.z,
-                             Q.abcd.z * p.x + Q.efgh.y * p.y + Q.efgh.w * p.z + Q.ij_mat.x));
+            f3 n = norm3(mk3(q[0] * p.x + q[1] * p.y + q[2] * p.z + q[3], q[1] * p.x + q[4] * p.y + q[5] * p.z + q[6],
+                             q[2] * p.x + q[5] * p.y + q[7] * p.z + q[8]));
             if (dot3(n, d) > 0.0f) n = -n;
             h.normal = n;
             h.has_tex = false;
@@ -639,7 +646,7 @@ __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t
             break;
         }
         case OP_MESH: {  // triangle_object.rs:85-160 for the winning triangle only
-            const MeshInfo &M = S.meshes[in.index];
+            const MeshInfo &M = S.meshes[in.aux];
             const TriHot T = S.tris[M.tri_first + sub];
             h.material = M.material;
             f3 n = mk3(T.a_nx.w, T.b_ny.w, T.c_nz.w);

@@ -278,17 +278,19 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_batch_trace(BatchTraceArgs A) {
         uint32_t prim = 0;
         if (ok) {
             eval_hit(A.S, o, d, tr.instr, tr.sub, tr.t, h);
-            Instr in = A.S.instrs[tr.instr];
-            ObjectRange R = A.S.objects[tr.object];
-            if (in.op == OP_MESH) {
-                const MeshInfo &M = A.S.meshes[in.index];
+            const ProgRec &in = A.S.prog[tr.instr];
+            uint32_t op = in.op & 0xFFu;
+            if (op == OP_MESH) {
+                const MeshInfo &M = A.S.meshes[in.aux];
                 prim = A.S.tri_index[M.tri_first + tr.sub];
-            } else if (R.count > 1) {  // leaf number in post-order
+            } else if (in.op & PF_CSG) {  // leaf number in post-order
                 uint32_t leaf = 0;
-                for (uint32_t k = R.first; k < tr.instr; k++)
-                    if (A.S.instrs[k].op < OP_CSG_UNION) leaf++;
+                for (uint32_t k = tr.instr; !(A.S.prog[k].op & PF_FIRST);) {
+                    k--;
+                    if ((A.S.prog[k].op & 0xFFu) < OP_CSG_UNION) leaf++;
+                }
                 prim = leaf;
-            } else if (in.op == OP_CUBOID) {
+            } else if (op == OP_CUBOID) {
                 prim = tr.sub;
             }
         }

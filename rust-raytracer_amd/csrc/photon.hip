@@ -152,12 +152,13 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
             f3 so = h.position + dir * 0.0001f, sd = dir;
             uint32_t sub = 1;
             const PhotonOut &dst = A.out[dest_absorb_default];
-            for (uint32_t obj = 0; obj < S.n_objects; obj++) {
-                ObjectRange R = S.objects[obj];
-                if (R.count == 1) {
+            CsgState csg;
+            for (uint32_t k = 0; k < S.n_prog; k++) {
+                const ProgRec &rec = S.prog[k];
+                if (!(rec.op & PF_CSG)) {
                     float t = 0.0f;
                     uint32_t sb;
-                    bool have = alive && single_entering_hit(S, S.instrs[R.first], so, sd, RRT_INF, lds, cnt, t, sb);
+                    bool have = alive && single_entering_hit(S, rec, so, sd, RRT_INF, lds, cnt, t, sb);
                     if (have && sub >= 64) {
                         err |= RRT_ERR_BIT_SHADOW_CAP;
                         have = false;
@@ -166,12 +167,14 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
                     store_photon(dst, have, p, sd, mk3(0, 0, 0), RRT_PHOTON_SHADOW, key_base + sub, err);
                     if (have) sub++;
                 } else {
-                    uint32_t slot = 0, n = 0;
-                    if (alive) csg_eval(S, R, so, sd, lds, cnt, slot, n);
+                    if (rec.op & PF_FIRST) csg.reset();
+                    if (alive) csg.step(rec, k, so, sd, lds, cnt);
+                    if (!(rec.op & PF_LAST)) continue;
+                    uint32_t slot = csg.out_slot(), n = alive ? csg.out_len() : 0;
                     for (uint32_t e = 0; e < RRT_LIST_CAP; e++) {
                         bool have = false;
                         float t = 0.0f;
-                        if (alive && e < n) {
+                        if (e < n) {
                             t = lds.t(slot, e);
                             have = (lds.m(slot, e) & META_ENTER) && !(t < 0.0f);
                         }

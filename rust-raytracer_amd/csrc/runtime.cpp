@@ -65,14 +65,8 @@ DevPhotonMap PhotonIndex::view() const {
 namespace {
 
 struct Flat {
-    std::vector<Instr> instrs;
-    std::vector<ObjectRange> objects;
-    std::vector<float4> plane_hot;
+    std::vector<ProgRec> prog;
     std::vector<PlaneCold> plane_cold;
-    std::vector<float4> sphere_hot;
-    std::vector<int32_t> sphere_mat;
-    std::vector<CuboidHot> cuboid_hot;
-    std::vector<QuadricHot> quadric_hot;
     std::vector<MeshInfo> meshes;
     std::vector<TriHot> tris;
     std::vector<uint32_t> tri_index;
@@ -83,9 +77,10 @@ struct Flat {
 };
 
 uint32_t add_plane(Flat &F, f3 point, f3 up, f3 normal, float d, int material) {
-    uint32_t idx = (uint32_t)F.plane_hot.size();
-    F.plane_hot.push_back(make_float4(normal.x, normal.y, normal.z, d));
+    uint32_t idx = (uint32_t)F.plane_cold.size();
     PlaneCold c;
+    c.normal = normal;
+    c.d = d;
     c.centre = point;
     c.v_unit = norm3(up);                         // plane_object.rs:96
     c.u_unit = norm3(cross3(c.v_unit, normal));   // plane_object.rs:97
@@ -98,20 +93,31 @@ uint32_t add_plane(Flat &F, f3 point, f3 up, f3 normal, float d, int material) {
     return idx;
 }
 
+ProgRec &push_rec(Flat &F, uint32_t op, int material, uint32_t aux) {
+    ProgRec r;
+    memset(&r, 0, sizeof(r));
+    r.op = op;
+    r.material = material;
+    r.aux = aux;
+    F.prog.push_back(r);
+    return F.prog.back();
+}
+
 void emit(Flat &F, const HostObject &o) {
     switch (o.kind) {
         case RRT_OBJ_PLANE: {
             uint32_t idx = add_plane(F, o.p0, o.p1, o.p2, o.d, o.material);
-            F.instrs.push_back({OP_PLANE, idx});
+            ProgRec &r = push_rec(F, OP_PLANE, o.material, idx);
+            r.p[0] = o.p2.x, r.p[1] = o.p2.y, r.p[2] = o.p2.z, r.p[3] = o.d;
             F.flops += 18;
             break;
         }
-        case RRT_OBJ_SPHERE:
-            F.instrs.push_back({OP_SPHERE, (uint32_t)F.sphere_hot.size()});
-            F.sphere_hot.push_back(make_float4(o.p0.x, o.p0.y, o.p0.z, o.radius));
-            F.sphere_mat.push_back(o.material);
+        case RRT_OBJ_SPHERE: {
+            ProgRec &r = push_rec(F, OP_SPHERE, o.material, 0);
+            r.p[0] = o.p0.x, r.p[1] = o.p0.y, r.p[2] = o.p0.z, r.p[3] = o.radius;
             F.flops += 35;
             break;
+        }
         case RRT_OBJ_CUBOID: {  // cuboid_object.rs:58-90, plane order = CuboidPlanes::iter (:27-37)
             f3 corner = o.p0, size = o.p1;
             f3 fdl = corner;
@@ -123,28 +129,22 @@ void emit(Flat &F, const HostObject &o) {
                 f3 pt, up, n;
             } pl[6] = {{fdl, up, left}, {bdr, up, right}, {ful, fw, up}, {fdl, fw, down}, {fdl, up, bw}, {bdl, down, fw}};
             uint32_t first = 0;
+            float dd[6];
             for (int k = 0; k < 6; k++) {
-                uint32_t idx = add_plane(F, pl[k].pt, pl[k].up, pl[k].n, -dot3(pl[k].n, pl[k].pt), o.material);
+                dd[k] = -dot3(pl[k].n, pl[k].pt);
+                uint32_t idx = add_plane(F, pl[k].pt, pl[k].up, pl[k].n, dd[k], o.material);
                 if (k == 0) first = idx;
             }
-            CuboidHot c;
-            c.lo = make_float4(corner.x - 0.0001f, corner.y - 0.0001f, corner.z - 0.0001f, 0.0f);
-            c.hi = make_float4(corner.x + size.x + 0.0001f, corner.y + size.y + 0.0001f, corner.z + size.z + 0.0001f, 0.0f);
-            memcpy(&c.lo.w, &first, 4);
-            F.instrs.push_back({OP_CUBOID, (uint32_t)F.cuboid_hot.size()});
-            F.cuboid_hot.push_back(c);
+            ProgRec &r = push_rec(F, OP_CUBOID, o.material, first);
+            r.p[0] = corner.x - 0.0001f, r.p[1] = corner.y - 0.0001f, r.p[2] = corner.z - 0.0001f;
+            r.p[3] = corner.x + size.x + 0.0001f, r.p[4] = corner.y + size.y + 0.0001f, r.p[5] = corner.z + size.z + 0.0001f;
+            for (int k = 0; k < 6; k++) r.p[6 + k] = dd[k];
             F.flops += 6 * 18 + 6 * 12;
             break;
         }
         case RRT_OBJ_QUADRATIC: {
-            QuadricHot q;
-            q.abcd = make_float4(o.q[0], o.q[1], o.q[2], o.q[3]);
-            q.efgh = make_float4(o.q[4], o.q[5], o.q[6], o.q[7]);
-            q.ij_mat = make_float4(o.q[8], o.q[9], 0.0f, 0.0f);
-            int32_t m = o.material;
-            memcpy(&q.ij_mat.z, &m, 4);
-            F.instrs.push_back({OP_QUADRIC, (uint32_t)F.quadric_hot.size()});
-            F.quadric_hot.push_back(q);
+            ProgRec &r = push_rec(F, OP_QUADRIC, o.material, 0);
+            for (int k = 0; k < 10; k++) r.p[k] = o.q[k];
             F.flops += 95;
             break;
         }
@@ -180,14 +180,14 @@ void emit(Flat &F, const HostObject &o) {
                 F.tri_index.push_back(order[k]);
             }
             F.tri_normals.insert(F.tri_normals.end(), o.tri_nrm.begin(), o.tri_nrm.end());
-            F.instrs.push_back({OP_MESH, (uint32_t)F.meshes.size()});
+            push_rec(F, OP_MESH, o.material, (uint32_t)F.meshes.size());
             F.meshes.push_back(mi);
             break;
         }
         case RRT_OBJ_CSG:
             emit(F, *o.left);
             emit(F, *o.right);
-            F.instrs.push_back({(uint32_t)(OP_CSG_UNION + o.csg_mode), 0u});
+            push_rec(F, (uint32_t)(OP_CSG_UNION + o.csg_mode), -1, 0);
             break;
     }
 }
@@ -253,21 +253,21 @@ int flatten_scene(rrt_scene *s) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(RRT_ERR_DEVICE, "no HIP device: librrt has no CPU fallback");
     Flat F;
-    uint32_t max_stack = 0, max_prog = 1;
+    uint32_t max_stack = 0;
     bool has_csg = false;
-    for (auto &o : s->objects) {
-        ObjectRange r;
-        r.first = (uint32_t)F.instrs.size();
-        emit(F, *o);
-        r.count = (uint32_t)F.instrs.size() - r.first;
-        F.objects.push_back(r);
-        max_prog = std::max(max_prog, r.count);
-        if (r.count > 1) {
+    for (size_t oi = 0; oi < s->objects.size(); oi++) {
+        uint32_t first = (uint32_t)F.prog.size();
+        emit(F, *s->objects[oi]);
+        uint32_t count = (uint32_t)F.prog.size() - first;
+        for (uint32_t k = 0; k < count; k++) F.prog[first + k].object = (uint32_t)oi;
+        F.prog[first].op |= PF_FIRST;
+        F.prog[first + count - 1].op |= PF_LAST;
+        if (count > 1) {
             has_csg = true;
-            if (r.count > 0xFFFF) return fail(RRT_ERR_LIMIT, "CSG program longer than 65535 instructions");
             uint32_t sp = 0;
-            for (uint32_t k = 0; k < r.count; k++) {
-                if (F.instrs[r.first + k].op < OP_CSG_UNION)
+            for (uint32_t k = 0; k < count; k++) {
+                F.prog[first + k].op |= PF_CSG;
+                if ((F.prog[first + k].op & 0xFFu) < OP_CSG_UNION)
                     sp++;
                 else
                     sp--;
@@ -275,6 +275,8 @@ int flatten_scene(rrt_scene *s) {
             }
         }
     }
+    // the hit lists keep the record index of each hit in 16 bits (mk_meta in dev_trace.h)
+    if (has_csg && F.prog.size() > 0xFFFF) return fail(RRT_ERR_LIMIT, "scene with CSG objects has more than 65535 primitive records");
     DeviceScene &D = s->dev;
     D.lds_slots = has_csg ? max_stack + 1 : 0;
     if (D.lds_slots > 8) return fail(RRT_ERR_LIMIT, "CSG tree needs more than 7 live hit lists");
@@ -327,14 +329,8 @@ int flatten_scene(rrt_scene *s) {
 
 #define UP(field, vec)                      \
     if ((rc = D.field.upload(vec))) return rc;
-    UP(instrs, F.instrs)
-    UP(objects, F.objects)
-    UP(plane_hot, F.plane_hot)
+    UP(prog, F.prog)
     UP(plane_cold, F.plane_cold)
-    UP(sphere_hot, F.sphere_hot)
-    UP(sphere_mat, F.sphere_mat)
-    UP(cuboid_hot, F.cuboid_hot)
-    UP(quadric_hot, F.quadric_hot)
     UP(meshes, F.meshes)
     UP(tris, F.tris)
     UP(tri_index, F.tri_index)
@@ -347,18 +343,12 @@ int flatten_scene(rrt_scene *s) {
     UP(lights, lights)
 #undef UP
     DevScene &V = D.view;
-    V.instrs = D.instrs.p;
-    V.objects = D.objects.p;
-    V.n_objects = (uint32_t)F.objects.size();
+    V.prog = D.prog.p;
+    V.n_prog = (uint32_t)F.prog.size();
+    V.n_objects = (uint32_t)s->objects.size();
     V.n_lights = (uint32_t)lights.size();
-    V.max_program = max_prog;
     V.has_csg = has_csg ? 1 : 0;
-    V.plane_hot = D.plane_hot.p;
     V.plane_cold = D.plane_cold.p;
-    V.sphere_hot = D.sphere_hot.p;
-    V.sphere_mat = D.sphere_mat.p;
-    V.cuboid_hot = D.cuboid_hot.p;
-    V.quadric_hot = D.quadric_hot.p;
     V.meshes = D.meshes.p;
     V.tris = D.tris.p;
     V.tri_index = D.tri_index.p;

@@ -57,14 +57,8 @@ struct LevelStorage {
 };
 
 struct DeviceScene {
-    DBuf<Instr> instrs;
-    DBuf<ObjectRange> objects;
-    DBuf<float4> plane_hot;
+    DBuf<ProgRec> prog;
     DBuf<PlaneCold> plane_cold;
-    DBuf<float4> sphere_hot;
-    DBuf<int32_t> sphere_mat;
-    DBuf<CuboidHot> cuboid_hot;
-    DBuf<QuadricHot> quadric_hot;
     DBuf<MeshInfo> meshes;
     DBuf<TriHot> tris;
     DBuf<uint32_t> tri_index;
