@@ -24,7 +24,8 @@ enum Op : uint32_t {
     OP_MESH = 4,
     OP_CSG_UNION = 5,
     OP_CSG_INTERSECTION = 6,
-    OP_CSG_DIFFERENCE = 7
+    OP_CSG_DIFFERENCE = 7,
+    OP_BOUND = 8  // conservative box around the object that follows; a wave whose rays all miss it skips `aux` records
 };
 // One 64-byte record per instruction, primitive parameters inline: the trace loop streams through ONE array with
 // wave-uniform sequential addresses (scalar loads, no dependent index -> data chains).
@@ -34,6 +35,7 @@ enum Op : uint32_t {
 //                                                   aux = plane_cold index of the first of its 6 planes
 //   quadric p = a b c d e f g h i j
 //   mesh                                            aux = mesh index
+//   bound   p = lo.xyz, hi.xyz (padded), p[6] = origin-relative pad    aux = records to skip on a miss
 struct ProgRec {
     uint32_t op;      // Op in bits 0..7 | PF_* flags
     uint32_t object;  // index into Environment::objects()
@@ -112,6 +114,7 @@ struct DevScene {
     uint32_t n_objects;
     uint32_t n_lights;
     uint32_t has_csg;
+    uint32_t has_bounds;
     const PlaneCold *plane_cold;
     const MeshInfo *meshes;
     const TriHot *tris;        // BVH order

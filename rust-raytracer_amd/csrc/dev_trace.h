@@ -490,6 +490,36 @@ __device__ __forceinline__ bool csg_first_hit(Lds &lds, uint32_t slot, uint32_t 
     return have;
 }
 
+// ---- object bounds ----------------------------------------------------------------------------------
+// The reference tests every ray against every object.  A cuboid can only report a hit whose point lies inside its
+// (slack-expanded) box, and a CSG list is empty whenever the list of the operand that gates it is empty
+// (csg_object.rs:39-108: intersection and difference emit nothing without hits of the left / both operands), so a
+// ray that misses a conservatively padded box around those cuboids cannot produce a hit: skipping the object's
+// records leaves every result bit-identical.  The skip is wave-uniform (all lanes must miss).
+struct RayBox {
+    f3 inv;
+    float omax;
+};
+__device__ __forceinline__ RayBox make_raybox(f3 o, f3 d) {
+    RayBox b;
+    // 1-ulp reciprocals: their error is inside the 2^-20 widening of bound_hit
+    b.inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    b.omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    return b;
+}
+__device__ __forceinline__ bool bound_hit(const ProgRec &r, const RayBox &rb, f3 o) {
+    float e = rb.omax * r.p[6];
+    float x0 = (r.p[0] - (o.x + e)) * rb.inv.x, x1 = (r.p[3] - (o.x - e)) * rb.inv.x;
+    float y0 = (r.p[1] - (o.y + e)) * rb.inv.y, y1 = (r.p[4] - (o.y - e)) * rb.inv.y;
+    float z0 = (r.p[2] - (o.z + e)) * rb.inv.z, z1 = (r.p[5] - (o.z - e)) * rb.inv.z;
+    // fminf/fmaxf drop NaNs (0 * inf when the origin lies on a slab plane of a parallel ray)
+    float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    const float k = 9.5367431640625e-7f;  // 2^-20
+    float nc = n - fabsf(n) * k, fc = f + fabsf(f) * k;
+    return nc <= fc && fc >= 0.0f;
+}
+
 // One step of the object loop shared by trace and shadowtrace: feeds record k, and reports the object's first
 // entering hit once the object's last record has been consumed.
 __device__ __forceinline__ bool object_step(const DevScene &S, uint32_t k, const ProgRec &r, CsgState &csg, f3 o, f3 d, float bound, Lds &lds,
@@ -511,8 +541,14 @@ __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, C
     r.instr = 0;
     r.sub = 0;
     CsgState csg;
+    RayBox rb;
+    if (S.has_bounds) rb = make_raybox(o, d);
     for (uint32_t k = 0; k < S.n_prog; k++) {
         const ProgRec &rec = S.prog[k];
+        if ((rec.op & 0xFFu) == OP_BOUND) {
+            if (!__any(bound_hit(rec, rb, o))) k += rec.aux;
+            continue;
+        }
         float t;
         uint32_t kk, sub;
         if (!object_step(S, k, rec, csg, o, d, r.t, lds, cnt, t, kk, sub)) continue;
@@ -529,8 +565,14 @@ __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, C
 __device__ __forceinline__ bool shadowtrace(const DevScene &S, f3 o, f3 d, float limit, Lds &lds, Counters &cnt) {
     cnt.shadow++;
     CsgState csg;
+    RayBox rb;
+    if (S.has_bounds) rb = make_raybox(o, d);
     for (uint32_t k = 0; k < S.n_prog; k++) {
         const ProgRec &rec = S.prog[k];
+        if ((rec.op & 0xFFu) == OP_BOUND) {
+            if (!__any(bound_hit(rec, rb, o))) k += rec.aux;
+            continue;
+        }
         float t;
         uint32_t kk, sub;
         // for meshes only hits below `limit` matter: the closest hit is either below it (and found)

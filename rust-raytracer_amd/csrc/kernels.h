@@ -36,7 +36,8 @@ struct TraceArgs {
     uint32_t max_depth;   // Scene: global_material.rs:72 (5); PhotonScene: max_vueon_depth
     uint32_t mode;        // rrt_mode
     uint32_t y0;          // first image row of the band being rendered
-    uint32_t pixel_base;  // first pixel (band-relative) of this chunk
+    uint32_t pixel_base;  // first node (band-relative) of this chunk
+    uint32_t band_rows;   // rows of the band being rendered (camera renders)
     uint32_t lds_slots;   // hit-list slots per lane (0 = scene has no CSG)
     float gather_half_width;
     uint32_t *next_count;

@@ -62,6 +62,25 @@ __device__ __forceinline__ void camera_ray(const DevCamera &C, uint32_t x, uint3
     o = C.position;
 }
 
+// Camera renders walk the band in 8x8 pixel tiles (one wave = one tile): neighbouring rays hit and miss the same
+// objects, which is what the wave-uniform bound skip and the shading branches want.  Pixels right of the last full
+// tile column, then rows below the last full tile row, follow in row-major order.  Returns the band-relative pixel.
+__device__ __forceinline__ uint32_t node_pixel(uint32_t g, uint32_t width, uint32_t rows) {
+    uint32_t tiles_x = width >> 3, full_rows = rows & ~7u;
+    uint32_t tiled = tiles_x * 8u * full_rows;
+    if (g < tiled) {
+        uint32_t tile = g >> 6, in = g & 63u;
+        uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        return (ty * 8u + (in >> 3)) * width + tx * 8u + (in & 7u);
+    }
+    uint32_t r = g - tiled, wrem = width - tiles_x * 8u;
+    if (r < wrem * full_rows) {
+        uint32_t y = r / wrem;
+        return y * width + tiles_x * 8u + (r - y * wrem);
+    }
+    return full_rows * width + (r - wrem * full_rows);
+}
+
 #ifndef RRT_MIN_WAVES
 #define RRT_MIN_WAVES 1
 #endif
@@ -81,7 +100,7 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
     if (active) {
         f3 o, d;
         if (A.level == 0 && A.cam.width != 0) {
-            uint32_t pixel = A.pixel_base + i;
+            uint32_t pixel = node_pixel(A.pixel_base + i, A.cam.width, A.band_rows);
             camera_ray(A.cam, pixel % A.cam.width, A.y0 + pixel / A.cam.width, o, d);
         } else {
             float4 ro = A.cur.ray_o[i], rd = A.cur.ray_d[i];
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
     }
     A.cur.result[i] = make_float4(colour.x, colour.y, colour.z, res.w);
     if (A.level == 0) {
-        uint32_t pixel = A.pixel_base + i;
+        uint32_t pixel = A.cam.width ? node_pixel(A.pixel_base + i, A.cam.width, A.band_rows) : A.pixel_base + i;
         if (A.out_rgb) {
             A.out_rgb[(size_t)pixel * 3 + 0] = colour.x;
             A.out_rgb[(size_t)pixel * 3 + 1] = colour.y;

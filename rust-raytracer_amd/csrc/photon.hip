@@ -153,8 +153,14 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
             uint32_t sub = 1;
             const PhotonOut &dst = A.out[dest_absorb_default];
             CsgState csg;
+            RayBox rb;
+            if (S.has_bounds) rb = make_raybox(so, sd);
             for (uint32_t k = 0; k < S.n_prog; k++) {
                 const ProgRec &rec = S.prog[k];
+                if ((rec.op & 0xFFu) == OP_BOUND) {
+                    if (!__any(alive && bound_hit(rec, rb, so))) k += rec.aux;
+                    continue;
+                }
                 if (!(rec.op & PF_CSG)) {
                     float t = 0.0f;
                     uint32_t sb;

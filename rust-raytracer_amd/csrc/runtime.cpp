@@ -192,6 +192,53 @@ void emit(Flat &F, const HostObject &o) {
     }
 }
 
+// Conservative box for the skip test of dev_trace.h "object bounds".  finite == false: never skipped.
+struct Box {
+    bool finite = false;
+    float lo[3], hi[3];
+    float area() const {
+        float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x * y + y * z + z * x;
+    }
+};
+Box bound_of(const HostObject &o) {
+    Box b;
+    switch (o.kind) {
+        case RRT_OBJ_CUBOID: {  // hits must pass the inside test of cuboid_object.rs:107-112
+            const float c[3] = {o.p0.x, o.p0.y, o.p0.z}, sz[3] = {o.p1.x, o.p1.y, o.p1.z};
+            b.finite = true;
+            for (int a = 0; a < 3; a++) {
+                b.lo[a] = c[a] - 0.0001f;
+                b.hi[a] = c[a] + sz[a] + 0.0001f;
+                if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) b.finite = false;
+            }
+            break;
+        }
+        case RRT_OBJ_CSG: {
+            Box l = bound_of(*o.left), r = bound_of(*o.right);
+            if (o.csg_mode == RRT_CSG_UNION) {  // no hits unless one operand has hits
+                if (l.finite && r.finite) {
+                    b.finite = true;
+                    for (int a = 0; a < 3; a++) {
+                        b.lo[a] = std::min(l.lo[a], r.lo[a]);
+                        b.hi[a] = std::max(l.hi[a], r.hi[a]);
+                    }
+                }
+            } else if (o.csg_mode == RRT_CSG_INTERSECTION) {  // no hits unless BOTH operands have hits: either box will do
+                if (l.finite && r.finite)
+                    b = l.area() <= r.area() ? l : r;
+                else
+                    b = l.finite ? l : r;
+            } else {  // difference: no hits unless the left operand has hits
+                b = l;
+            }
+            break;
+        }
+        default: break;  // planes and quadrics: unbounded or not worth a test; meshes: their BVH root does this
+    }
+    return b;
+}
+
 int flatten_materials(rrt_scene *s, std::vector<DevMaterial> &out, bool &reflective) {
     reflective = false;
     auto part_of = [](const rrt_material_desc &d) {
@@ -254,11 +301,28 @@ int flatten_scene(rrt_scene *s) {
         return fail(RRT_ERR_DEVICE, "no HIP device: librrt has no CPU fallback");
     Flat F;
     uint32_t max_stack = 0;
-    bool has_csg = false;
+    bool has_csg = false, has_bounds = false;
     for (size_t oi = 0; oi < s->objects.size(); oi++) {
+        const HostObject &ho = *s->objects[oi];
+        Box bb = bound_of(ho);
+        int bound_rec = -1;
+        if (bb.finite && !getenv("RRT_NO_BOUNDS")) {
+            bound_rec = (int)F.prog.size();
+            ProgRec &r = push_rec(F, OP_BOUND, -1, 0);
+            for (int a = 0; a < 3; a++) {
+                // absolute pad: rounding of o + d*t at the box's own coordinate magnitude, with a wide margin
+                float mag = std::max(std::fabs(bb.lo[a]), std::fabs(bb.hi[a])) + std::fabs(bb.hi[a] - bb.lo[a]);
+                float pad = 1e-4f * mag + 1e-4f;
+                r.p[a] = bb.lo[a] - pad;
+                r.p[3 + a] = bb.hi[a] + pad;
+            }
+            r.p[6] = 3.2e-5f;  // pad per unit of |origin|: rounding of o + d*t for far origins (error <~ 1e-6 |o|)
+            has_bounds = true;
+        }
         uint32_t first = (uint32_t)F.prog.size();
-        emit(F, *s->objects[oi]);
+        emit(F, ho);
         uint32_t count = (uint32_t)F.prog.size() - first;
+        if (bound_rec >= 0) F.prog[bound_rec].aux = count;
         for (uint32_t k = 0; k < count; k++) F.prog[first + k].object = (uint32_t)oi;
         F.prog[first].op |= PF_FIRST;
         F.prog[first + count - 1].op |= PF_LAST;
@@ -348,6 +412,7 @@ int flatten_scene(rrt_scene *s) {
     V.n_objects = (uint32_t)s->objects.size();
     V.n_lights = (uint32_t)lights.size();
     V.has_csg = has_csg ? 1 : 0;
+    V.has_bounds = has_bounds ? 1 : 0;
     V.plane_cold = D.plane_cold.p;
     V.meshes = D.meshes.p;
     V.tris = D.tris.p;
@@ -411,6 +476,7 @@ int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixe
         A.mode = (uint32_t)s->mode;
         A.y0 = y0;
         A.pixel_base = base;
+        A.band_rows = cam && cam->width ? n_pixels / cam->width : 0;
         A.lds_slots = D.lds_slots;
         A.gather_half_width = s->params.gather_half_width;
         A.err = err_dev;

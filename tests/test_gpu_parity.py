@@ -59,6 +59,28 @@ def test_frames_match_oracle_in_raytracing_mode(repo, name):
             assert sg[k] == sc[k], k
 
 
+@pytest.mark.parametrize("size", [(37, 21), (8, 8), (5, 3), (67, 9)])
+def test_ragged_frame_sizes_bands_and_chunks(repo, size):
+    """The band is walked in 8x8 tiles with ragged right / bottom edges and split into chunks: every pixel must
+    still land where the reference's row-major loop (camera.rs:14-42) puts it."""
+    cpu, gpu, cam = load_pair(repo, "c2_quadric_csg_fresnel")
+    cam.width, cam.height = size
+    gpu.pre_render(1)
+    rgb_c, depth_c, id_c = cpu.render(cam)
+    rgb_g, depth_g, id_g = gpu.render(cam)
+    assert np.array_equal(id_g, id_c) and np.array_equal(bits(depth_g), bits(depth_c))
+    assert np.abs(rrt.quantise(rgb_g).astype(int) - ob.quantise(rgb_c).astype(int)).max() <= 1
+    # a band of rows (what one rank of a multi-GPU render does) and a chunk size that is no multiple of a tile
+    y0, y1 = size[1] // 3, size[1]
+    p = rrt.default_params()
+    p.chunk_pixels = 100
+    gpu.set_params(p)
+    gpu.pre_render(1)
+    rgb_b, depth_b, id_b = gpu.render(cam, y0, y1)
+    assert np.array_equal(id_b, id_c[y0:y1]) and np.array_equal(bits(depth_b), bits(depth_c[y0:y1]))
+    assert np.array_equal(bits(rgb_b), bits(rgb_g[y0:y1]))
+
+
 @pytest.mark.parametrize("name", REFERENCE_SCENES)
 def test_trace_and_shadowtrace_match_oracle_on_random_rays(repo, name):
     cpu, gpu, cam = load_pair(repo, name)
