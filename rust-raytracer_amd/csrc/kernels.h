@@ -24,6 +24,9 @@ struct DevPhotonMap {
     float inv_cell;
 };
 
+// error bits of TraceArgs::err (1, 2, 4: dev_shade.h)
+#define RRT_ERR_BIT_QUEUE 8u  // a level queue outgrew the size predicted from the previous frame (internal: retried)
+
 enum StatSlot { ST_NODES = 0, ST_TRIS, ST_SHADOW, ST_GATHERED, ST_QUERIES, ST_CANDIDATES, ST_COUNT };
 
 struct TraceArgs {
@@ -31,7 +34,9 @@ struct TraceArgs {
     LevelBuffers cur, next;
     DevCamera cam;
     DevPhotonMap maps[2];
-    uint32_t count;       // rays in this level
+    uint32_t count;       // rays in this level; an upper bound (the launch size) when count_ptr is set
+    const uint32_t *count_ptr;  // device-side count written by the previous level's appends, or null
+    uint32_t next_limit;  // rays the next level's launch will cover: appends beyond it raise RRT_ERR_BIT_QUEUE
     uint32_t level;       // recursion depth of these rays
     uint32_t max_depth;   // Scene: global_material.rs:72 (5); PhotonScene: max_vueon_depth
     uint32_t mode;        // rrt_mode

@@ -91,7 +91,9 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
     const DevScene &S = A.S;
     Lds lds = make_lds(A.lds_slots);
     uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
-    bool active = i < A.count;
+    uint32_t count = A.count_ptr ? min(*A.count_ptr, A.count) : A.count;
+    bool active = i < count;
+    if (blockIdx.x * RRT_BLOCK >= count) return;  // launched for the predicted size of the level
     Counters cnt = {0, 0, 0, 0};
     unsigned long long gathered = 0, queries = 0, candidates = 0;
     bool want_a = false, want_b = false;  // a: reflection child, b: refraction child
@@ -196,6 +198,10 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(A.next_count, total);
         base = __shfl(base, 0, 64);
+        if (base + total > A.next_limit) {  // prediction too small: the host repeats the frame level by level
+            if (lane == 0) atomicOr(A.err, RRT_ERR_BIT_QUEUE);
+            want_a = want_b = false;
+        }
         unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
         uint32_t off = base + __popcll(ma & below) + __popcll(mb & below);
         if (want_a) {
@@ -216,7 +222,8 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
 
 __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
     uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
-    if (i >= A.count) return;
+    uint32_t count = A.count_ptr ? min(*A.count_ptr, A.count) : A.count;
+    if (i >= count) return;
     float4 g = A.cur.glob[i];
     uint32_t flags = __float_as_uint(g.w);
     float4 res = A.cur.result[i];

@@ -442,10 +442,16 @@ int ensure_workspace(rrt_scene *s) {
 }
 
 // The render loop: one chunk of pixels at a time, one queue per recursion level.
-int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
-                const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream) {
-    if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
-    if (s->mode == RRT_MODE_PHOTON && !s->maps_built) return fail(RRT_ERR_STATE, "Photon map not built");
+// One frame (or ray batch) through the level queues.
+//
+// The size of level k+1 is only known once level k has run.  The first frame of a given size finds the sizes out level
+// by level (one 4-byte readback + stream sync per level).  Later frames launch every level for the sizes the previous
+// frame had (+12.5 % + 4096) without waiting, read all counters back once at the end, and fall back to the
+// level-by-level path if a queue outgrew its prediction (RRT_ERR_BIT_QUEUE; nothing is written past a launch's reach).
+static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
+                            const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream,
+                            bool allow_predicted, bool &retry) {
+    retry = false;
     DeviceScene &D = s->dev;
     const uint32_t n_lights = D.view.n_lights;
     const uint32_t depth_cap = s->mode == RRT_MODE_SCENE ? s->params.max_depth : s->params.max_vueon_depth;
@@ -460,10 +466,12 @@ int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixe
     RRT_HIP(hipEventRecord(s->events[0], stream));
     uint64_t secondary = 0;
     float ms_trace = 0.0f;
+    std::vector<uint32_t> &pred = s->level_prediction;  // [0] = chunk size it was measured on, [1 + k] = size of level k
     for (uint32_t base = 0; base < n_pixels; base += chunk) {
         uint32_t n = std::min(chunk, n_pixels - base);
-        std::vector<uint32_t> counts(n_levels + 1, 0);
-        counts[0] = n;
+        std::vector<uint32_t> counts(n_levels + 1, 0), caps(n_levels + 1, 0);
+        counts[0] = caps[0] = n;
+        const bool predicted = allow_predicted && n_levels > 1 && pred.size() == n_levels + 2 && pred[0] == n;
         if ((rc = s->levels[0].ensure(n, n_lights, cam == nullptr))) return rc;
         if (!cam) launch_load_rays(origins_dev + (size_t)base * 3, directions_dev + (size_t)base * 3, n, s->levels[0].view(), stream);
         TraceArgs A;
@@ -486,39 +494,90 @@ int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixe
         A.out_id = id_dev;
         uint32_t last = 0;
         RRT_HIP(hipMemsetAsync(s->counters.p, 0, 60 * sizeof(uint32_t), stream));
-        for (uint32_t k = 0; k < n_levels; k++) {
-            bool spawns = k + 1 < n_levels;
-            if (spawns && (rc = s->levels[k + 1].ensure(2 * counts[k], n_lights, true))) return rc;
-            A.cur = s->levels[k].view();
-            A.next = s->levels[k + 1].view();
-            A.count = counts[k];
-            A.level = k;
-            A.next_count = s->counters.p + (k + 1);
+        if (predicted) {
+            for (uint32_t k = 1; k < n_levels; k++) {
+                uint64_t want = (uint64_t)pred[1 + k] + pred[1 + k] / 8 + 4096;
+                caps[k] = (uint32_t)std::min<uint64_t>(want, 2ull * caps[k - 1]);
+                if ((rc = s->levels[k].ensure(caps[k], n_lights, true))) return rc;
+            }
+            if ((rc = s->levels[n_levels].ensure(1, n_lights, true))) return rc;
             RRT_HIP(hipEventRecord(s->events[2], stream));
-            launch_trace_shade(A, D.lds_bytes, stream);
+            for (uint32_t k = 0; k < n_levels; k++) {
+                A.cur = s->levels[k].view();
+                A.next = s->levels[k + 1].view();
+                A.count = caps[k];
+                A.count_ptr = k ? s->counters.p + k : nullptr;
+                A.next_limit = caps[k + 1];
+                A.level = k;
+                A.next_count = s->counters.p + (k + 1);
+                launch_trace_shade(A, D.lds_bytes, stream);
+            }
             RRT_HIP(hipEventRecord(s->events[3], stream));
-            last = k;
-            uint32_t next_n = 0;
-            if (spawns) {
-                RRT_HIP(hipMemcpyAsync(s->host_pinned, s->counters.p + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                RRT_HIP(hipStreamSynchronize(stream));
-                next_n = s->host_pinned[0];
-            } else {
-                RRT_HIP(hipStreamSynchronize(stream));
+            for (int k = (int)n_levels - 1; k >= 0; k--) {
+                A.cur = s->levels[k].view();
+                A.next = s->levels[k + 1].view();
+                A.count = caps[k];
+                A.count_ptr = k ? s->counters.p + k : nullptr;
+                A.level = (uint32_t)k;
+                launch_combine(A, stream);
+            }
+            RRT_HIP(hipMemcpyAsync(s->host_pinned, s->counters.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            RRT_HIP(hipStreamSynchronize(stream));
+            if (s->host_pinned[63] & RRT_ERR_BIT_QUEUE) {
+                pred.clear();
+                retry = true;
+                return RRT_OK;
+            }
+            for (uint32_t k = 1; k < n_levels; k++) {
+                counts[k] = s->host_pinned[k];
+                secondary += counts[k];
             }
             float ms = 0.0f;
             RRT_HIP(hipEventElapsedTime(&ms, s->events[2], s->events[3]));
             ms_trace += ms;
-            counts[k + 1] = next_n;
-            secondary += next_n;
-            if (next_n == 0) break;
+        } else {
+            for (uint32_t k = 0; k < n_levels; k++) {
+                bool spawns = k + 1 < n_levels;
+                if (spawns && (rc = s->levels[k + 1].ensure(2 * counts[k], n_lights, true))) return rc;
+                A.cur = s->levels[k].view();
+                A.next = s->levels[k + 1].view();
+                A.count = counts[k];
+                A.count_ptr = nullptr;
+                A.next_limit = spawns ? 2 * counts[k] : 0;
+                A.level = k;
+                A.next_count = s->counters.p + (k + 1);
+                RRT_HIP(hipEventRecord(s->events[2], stream));
+                launch_trace_shade(A, D.lds_bytes, stream);
+                RRT_HIP(hipEventRecord(s->events[3], stream));
+                last = k;
+                uint32_t next_n = 0;
+                if (spawns) {
+                    RRT_HIP(hipMemcpyAsync(s->host_pinned, s->counters.p + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    RRT_HIP(hipStreamSynchronize(stream));
+                    next_n = s->host_pinned[0];
+                } else {
+                    RRT_HIP(hipStreamSynchronize(stream));
+                }
+                float ms = 0.0f;
+                RRT_HIP(hipEventElapsedTime(&ms, s->events[2], s->events[3]));
+                ms_trace += ms;
+                counts[k + 1] = next_n;
+                secondary += next_n;
+                if (next_n == 0) break;
+            }
+            for (int k = (int)last; k >= 0; k--) {
+                A.cur = s->levels[k].view();
+                A.next = s->levels[k + 1].view();
+                A.count = counts[k];
+                A.count_ptr = nullptr;
+                A.level = (uint32_t)k;
+                launch_combine(A, stream);
+            }
         }
-        for (int k = (int)last; k >= 0; k--) {
-            A.cur = s->levels[k].view();
-            A.next = s->levels[k + 1].view();
-            A.count = counts[k];
-            A.level = (uint32_t)k;
-            launch_combine(A, stream);
+        if (n_levels > 1) {  // what the next frame of this size will be launched for
+            pred.assign(n_levels + 2, 0);
+            pred[0] = n;
+            for (uint32_t k = 0; k <= n_levels; k++) pred[1 + k] = counts[k];
         }
     }
     RRT_HIP(hipEventRecord(s->events[1], stream));
@@ -545,6 +604,18 @@ int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixe
     if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
     if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
     return RRT_OK;
+}
+
+int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
+                const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream) {
+    if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
+    if (s->mode == RRT_MODE_PHOTON && !s->maps_built) return fail(RRT_ERR_STATE, "Photon map not built");
+    static const bool level_sync = getenv("RRT_LEVEL_SYNC") != nullptr;  // debugging aid: always size levels by readback
+    bool retry = false;
+    int rc = render_rays_impl(s, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream, !level_sync, retry);
+    if (rc == RRT_OK && retry)
+        rc = render_rays_impl(s, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream, false, retry);
+    return rc;
 }
 
 }  // namespace rrt

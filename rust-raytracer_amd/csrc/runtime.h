@@ -115,6 +115,7 @@ struct rrt_scene {
     uint64_t seed = 0;
     rrt::DeviceScene dev;
     std::vector<rrt::LevelStorage> levels;
+    std::vector<uint32_t> level_prediction;  // level sizes of the previous frame, see render_rays
     rrt::DBuf<uint32_t> counters;             // per-level queue lengths + error word
     rrt::DBuf<unsigned long long> stats_dev;  // StatSlot counters
     uint32_t *host_pinned = nullptr;          // readback staging

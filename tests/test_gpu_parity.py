@@ -81,6 +81,35 @@ def test_ragged_frame_sizes_bands_and_chunks(repo, size):
     assert np.array_equal(bits(rgb_b), bits(rgb_g[y0:y1]))
 
 
+def test_predicted_level_sizes_and_their_fallback(repo):
+    """Frames after the first are launched for the previous frame's level sizes without per-level readbacks; a frame
+    that outgrows the prediction is repeated level by level.  Both must give the first frame's bits."""
+    cpu, gpu, cam = load_pair(repo, "c2_quadric_csg_fresnel")
+    cam.width, cam.height = 256, 160
+    gpu.pre_render(1)
+    first = gpu.render(cam)            # sizes found level by level
+    s1 = gpu.stats()
+    second = gpu.render(cam)           # predicted sizes
+    s2 = gpu.stats()
+    for a, b in zip(first, second):
+        assert np.array_equal(bits(a), bits(b))
+    for k in ("rays_primary", "rays_secondary", "rays_shadow"):
+        assert s1[k] == s2[k], k
+    # a camera that sees only sky leaves a prediction of zero secondary rays ...
+    away = rrt.make_camera(256, 160, 0.5, (0.0, 50.0, 0.0), (0.0, -1.0, 0.0), (0.0, 0.0, 1.0))  # file-space -y looks up
+    _, _, ids = gpu.render(away)
+    ids2 = gpu.render(away)[2]
+    assert (ids == abi.MISS).all() and (ids2 == abi.MISS).all() and gpu.stats()["rays_secondary"] == 0
+    # ... which the real view overflows by far: repeated transparently
+    third = gpu.render(cam)
+    s3 = gpu.stats()
+    for a, b in zip(first, third):
+        assert np.array_equal(bits(a), bits(b))
+    assert s3["rays_secondary"] == s1["rays_secondary"] and s3["rays_shadow"] == s1["rays_shadow"]
+    rgb_c, depth_c, id_c = cpu.render(cam)
+    assert np.array_equal(first[2], id_c) and np.array_equal(bits(first[1]), bits(depth_c))
+
+
 @pytest.mark.parametrize("name", REFERENCE_SCENES)
 def test_trace_and_shadowtrace_match_oracle_on_random_rays(repo, name):
     cpu, gpu, cam = load_pair(repo, name)
