@@ -115,6 +115,7 @@ struct DevScene {
     uint32_t n_lights;
     uint32_t has_csg;
     uint32_t has_bounds;
+    uint32_t n_plane_cold, n_meshes, n_materials;  // array sizes, for the device-side index guards
     const PlaneCold *plane_cold;
     const MeshInfo *meshes;
     const TriHot *tris;        // BVH order

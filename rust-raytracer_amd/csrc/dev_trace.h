@@ -26,16 +26,33 @@ __device__ __forceinline__ uint32_t mk_meta(bool entering, uint32_t instr, uint3
     return (entering ? META_ENTER : 0u) | (instr << 8) | sub;
 }
 
-// Per-block LDS views.  lists: [slot][entry][thread]; stack: [entry][thread] (aliases the lists:
-// meshes cannot be CSG leaves, so a lane never uses both at once).
+// Per-block LDS views.  lists: [slot][entry][thread] of 8-byte entries; the BVH stack aliases the lists (meshes
+// cannot be CSG leaves, so a lane never uses both at once) and therefore MUST stay inside the lane's own 8-byte
+// column: the other waves of the block are at other records, and a stack laid out as [entry][thread] of 4-byte words
+// would put lane t's words into the list columns of lanes t/2 of another wave.  Two stack words per column element.
+// tools/cpu_emu defines this to assert that an access stays inside the block's LDS allocation and inside the
+// accessing lane's own 8-byte column (argument: index of the 8-byte element)
+#ifndef RRT_LDS_CHECK
+#define RRT_LDS_CHECK(lds, elem)
+#endif
 struct Lds {
-    float *lt;
-    uint32_t *lm;
+    float2 *le;  // hit-list entries: (distance, meta word) as one 8-byte element -> ds_read_b64 / ds_write_b64
     int *stack;
     uint32_t nthreads, tid;
-    __device__ __forceinline__ float &t(uint32_t slot, uint32_t e) { return lt[(slot * RRT_LIST_CAP + e) * nthreads + tid]; }
-    __device__ __forceinline__ uint32_t &m(uint32_t slot, uint32_t e) { return lm[(slot * RRT_LIST_CAP + e) * nthreads + tid]; }
-    __device__ __forceinline__ int &st(uint32_t e) { return stack[e * nthreads + tid]; }
+    __device__ __forceinline__ void get(uint32_t slot, uint32_t e, float &t, uint32_t &m) const {
+        RRT_LDS_CHECK(*this, (slot * RRT_LIST_CAP + e) * nthreads + tid);
+        float2 v = le[(slot * RRT_LIST_CAP + e) * nthreads + tid];
+        t = v.x;
+        m = __float_as_uint(v.y);
+    }
+    __device__ __forceinline__ void put(uint32_t slot, uint32_t e, float t, uint32_t m) {
+        RRT_LDS_CHECK(*this, (slot * RRT_LIST_CAP + e) * nthreads + tid);
+        le[(slot * RRT_LIST_CAP + e) * nthreads + tid] = make_float2(t, __uint_as_float(m));
+    }
+    __device__ __forceinline__ int &st(uint32_t e) {
+        RRT_LDS_CHECK(*this, (e >> 1) * nthreads + tid);
+        return stack[(((e >> 1) * nthreads + tid) << 1) + (e & 1u)];
+    }
 };
 
 struct Counters {
@@ -121,9 +138,11 @@ __device__ __forceinline__ bool quadric_hits(const float *q, f3 P, f3 D, float &
 // replace on ties).  sub = plane * 2 + position of the hit in that plane's list.
 __device__ __forceinline__ void cuboid_hits(const ProgRec &C, f3 o, f3 d, bool &have_first, float &t_first, uint32_t &sub_first,
                                             bool &have_back, float &t_back, uint32_t &sub_back) {
-    have_first = have_back = false;
-    t_first = t_back = 0.0f;
-    sub_first = sub_back = 0;
+    // Branch-free restatement of the reference's loop: "no hit yet" is the sentinel -1 for the entering side (every
+    // accepted t is >= 0, so `!(have && t_first > t)` == `t_first <= t`) and +inf for the exit side (accepted t's are
+    // finite, so `!(have && t_back < t)` == `t_back >= t`).  NaN hit points fail the inside test as in the reference.
+    float tf = -1.0f, tb = RRT_INF;
+    uint32_t sf = 0, sb = 0;
     // plane order = CuboidPlanes::iter (cuboid_object.rs:27-37): left, right, up, down, front, back
     const f3 normals[6] = {{-1.0f, 0.0f, 0.0f}, {1.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f}, {0.0f, -1.0f, 0.0f}, {0.0f, 0.0f, -1.0f}, {0.0f, 0.0f, 1.0f}};
 #pragma unroll
@@ -131,26 +150,25 @@ __device__ __forceinline__ void cuboid_hits(const ProgRec &C, f3 o, f3 d, bool &
         f3 n = normals[p];
         float U = dot3(n, o) + C.p[6 + p];
         float V = dot3(n, d);
-        if (V == 0.0f) continue;  // both hits infinite: skipped at cuboid_object.rs:120-122
         float t = U / -V;
-        bool entering = !(V > 0.0f);
         f3 hp = o + d * t;
         bool inside = hp.x >= C.p[0] && hp.x <= C.p[3] && hp.y >= C.p[1] && hp.y <= C.p[4] && hp.z >= C.p[2] && hp.z <= C.p[5];
-        if (!inside) continue;
-        if (t < 0.0f) continue;
-        if (isinf(t)) continue;
-        if (entering) {
-            if (!(have_first && t_first > t)) {
-                have_first = true;
-                t_first = t;
-                sub_first = p * 2;  // list position 0 when V < 0
-            }
-        } else if (!(have_back && t_back < t)) {
-            have_back = true;
-            t_back = t;
-            sub_back = p * 2 + 1;  // list position 1 when V > 0
-        }
+        // V == 0: both hits infinite, skipped at cuboid_object.rs:120-122; then t < 0 and infinite t
+        bool valid = inside & (V != 0.0f) & !(t < 0.0f) & !isinf(t);
+        bool entering = !(V > 0.0f);
+        bool uf = valid & entering & (tf <= t);
+        bool ub = valid & !entering & (tb >= t);
+        tf = uf ? t : tf;
+        sf = uf ? p * 2 : sf;          // list position 0 when V < 0
+        tb = ub ? t : tb;
+        sb = ub ? p * 2 + 1 : sb;      // list position 1 when V > 0
     }
+    have_first = tf >= 0.0f;
+    have_back = tb < RRT_INF;
+    t_first = have_first ? tf : 0.0f;
+    t_back = have_back ? tb : 0.0f;
+    sub_first = sf;
+    sub_back = sb;
 }
 
 // ---- mesh: BVH2 traversal, per-lane stack in LDS ---------------------------------------------------
@@ -222,6 +240,10 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
     if (M.tri_count == 0) return false;
     for (;;) {
         if (cur >= 0) {
+            if ((uint32_t)cur >= M.node_count) {  // index guard: refuse a wild node id instead of faulting the GPU
+                cnt.overflow |= 16u;              // RRT_ERR_BIT_INTERNAL
+                break;
+            }
             const BvhNode N = nodes[cur];
             bool hl, hr;
             float nl, nr;
@@ -246,6 +268,10 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
         } else {
             uint32_t code = (uint32_t)(-(cur + 1));
             uint32_t first = code >> 4, n = code & 15u;
+            if (first + n > M.tri_count) {  // index guard, as above
+                cnt.overflow |= 16u;
+                break;
+            }
             for (uint32_t k = 0; k < n; k++) {
                 const TriHot T = tris[first + k];
                 float t;
@@ -283,9 +309,15 @@ __device__ __forceinline__ void csg_merge(uint32_t mode, Lds &lds, uint32_t sl, 
     uint32_t tab = mode == OP_CSG_UNION ? tab_union : (mode == OP_CSG_INTERSECTION ? tab_intersection : tab_difference);
     uint32_t li = 0, ri = 0;
     no = 0;
+    // heads of both lists live in registers; only the side that advanced is re-read (index clamped: the value read
+    // past the end of a list is never used)
+    float tl = 0.0f, tr = 0.0f;
+    uint32_t ml = 0, mr = 0;
+    lds.get(sl, 0, tl, ml);
+    lds.get(sr, 0, tr, mr);
+    nl = min(nl, (uint32_t)RRT_LIST_CAP);  // guards: lengths are <= 6 by construction, so the loop ends within 12 steps
+    nr = min(nr, (uint32_t)RRT_LIST_CAP);
     while (li < nl && ri < nr) {
-        float tl = lds.t(sl, li), tr = lds.t(sr, ri);
-        uint32_t ml = lds.m(sl, li), mr = lds.m(sr, ri);
         uint32_t state = ((ml & META_ENTER) ? 4u : 0u) + ((mr & META_ENTER) ? 2u : 0u) + ((tl > tr) ? 1u : 0u);
         uint32_t act = (tab >> (state * 4)) & 15u;
         bool is_b = (act & 4u) != 0;
@@ -295,15 +327,19 @@ __device__ __forceinline__ void csg_merge(uint32_t mode, Lds &lds, uint32_t sl, 
                 cnt.overflow = 1;  // reference: panic "HitVec overflow"
                 return;
             }
-            lds.t(so, no) = is_b ? tr : tl;
             uint32_t mm = (is_b ? mr : ml) & ~META_ENTER;
-            lds.m(so, no) = mm | (kind == 1 ? META_ENTER : 0u);
+            lds.put(so, no, is_b ? tr : tl, mm | (kind == 1 ? META_ENTER : 0u));
             no++;
         }
-        if (is_b)
-            ri++;
-        else
-            li++;
+        li += is_b ? 0u : 1u;
+        ri += is_b ? 1u : 0u;
+        float tn;
+        uint32_t mn;
+        lds.get(is_b ? sr : sl, min(is_b ? ri : li, (uint32_t)(RRT_LIST_CAP - 1)), tn, mn);
+        tl = is_b ? tl : tn;
+        ml = is_b ? ml : mn;
+        tr = is_b ? tn : tr;
+        mr = is_b ? mn : mr;
     }
     if (mode != OP_CSG_INTERSECTION) {
         for (; li < nl; li++) {
@@ -311,8 +347,10 @@ __device__ __forceinline__ void csg_merge(uint32_t mode, Lds &lds, uint32_t sl, 
                 cnt.overflow = 1;
                 return;
             }
-            lds.t(so, no) = lds.t(sl, li);
-            lds.m(so, no) = lds.m(sl, li);
+            float t;
+            uint32_t m;
+            lds.get(sl, li, t, m);
+            lds.put(so, no, t, m);
             no++;
         }
     }
@@ -322,8 +360,10 @@ __device__ __forceinline__ void csg_merge(uint32_t mode, Lds &lds, uint32_t sl, 
                 cnt.overflow = 1;
                 return;
             }
-            lds.t(so, no) = lds.t(sr, ri);
-            lds.m(so, no) = lds.m(sr, ri);
+            float t;
+            uint32_t m;
+            lds.get(sr, ri, t, m);
+            lds.put(so, no, t, m);
             no++;
         }
     }
@@ -339,22 +379,22 @@ __device__ __forceinline__ uint32_t leaf_list(const ProgRec &r, uint32_t k, f3 o
             float t0, t1;
             bool e0, e1;
             if (plane_hits(rec4(r), o, d, t0, e0, t1, e1) == 0) return 0;
-            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(e0, k, 0);
-            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(e1, k, 1);
+            lds.put(slot, 0, t0, mk_meta(e0, k, 0));
+            lds.put(slot, 1, t1, mk_meta(e1, k, 1));
             return 2;
         }
         case OP_SPHERE: {
             float t0, t1;
             if (!sphere_hits(rec4(r), o, d, t0, t1)) return 0;
-            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(true, k, 0);
-            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(false, k, 1);
+            lds.put(slot, 0, t0, mk_meta(true, k, 0));
+            lds.put(slot, 1, t1, mk_meta(false, k, 1));
             return 2;
         }
         case OP_QUADRIC: {
             float t0, t1;
             if (!quadric_hits(r.p, o, d, t0, t1)) return 0;
-            lds.t(slot, 0) = t0; lds.m(slot, 0) = mk_meta(true, k, 0);
-            lds.t(slot, 1) = t1; lds.m(slot, 1) = mk_meta(false, k, 1);
+            lds.put(slot, 0, t0, mk_meta(true, k, 0));
+            lds.put(slot, 1, t1, mk_meta(false, k, 1));
             return 2;
         }
         case OP_CUBOID: {
@@ -364,11 +404,11 @@ __device__ __forceinline__ uint32_t leaf_list(const ProgRec &r, uint32_t k, f3 o
             cuboid_hits(r, o, d, hf, tf, sf, hb, tb, sb);
             uint32_t n = 0;
             if (hf) {
-                lds.t(slot, n) = tf; lds.m(slot, n) = mk_meta(true, k, sf);
+                lds.put(slot, n, tf, mk_meta(true, k, sf));
                 n++;
             }
             if (hb) {
-                lds.t(slot, n) = tb; lds.m(slot, n) = mk_meta(false, k, sb);
+                lds.put(slot, n, tb, mk_meta(false, k, sb));
                 n++;
             }
             return n;
@@ -395,16 +435,39 @@ struct CsgState {
         } else {
             uint32_t sr = (stack_slots >> ((sp - 1) * 4)) & 15u, sl = (stack_slots >> ((sp - 2) * 4)) & 15u;
             uint32_t nr = (len_l >> ((sp - 1) * 4)) & 15u, nl = (len_l >> ((sp - 2) * 4)) & 15u;
-            uint32_t so = __builtin_ctz(free_mask);
-            uint32_t no;
-            csg_merge(op, lds, sl, nl, sr, nr, so, no, cnt);
-            free_mask &= ~(1u << so);
-            free_mask |= (1u << sl) | (1u << sr);
+            // Wave-uniform shortcuts (rays of a wave mostly miss the same operands).  With an empty operand the
+            // merge loop of csg_object.rs:52-91 does not run and only the tails are copied: the result IS the other
+            // operand's list (union, difference with empty right) or empty, so the slot is handed over as it is.
+            bool l_empty = !__any(nl != 0), r_empty = !__any(nr != 0);
+            uint32_t so, no;
+            if (r_empty && op != OP_CSG_INTERSECTION) {
+                so = sl, no = nl;
+                free_mask |= 1u << sr;
+            } else if (l_empty && op == OP_CSG_UNION) {
+                so = sr, no = nr;
+                free_mask |= 1u << sl;
+            } else if (l_empty || (r_empty && op == OP_CSG_INTERSECTION)) {
+                so = sl, no = 0;
+                free_mask |= 1u << sr;
+            } else {
+                so = __builtin_ctz(free_mask);
+                csg_merge(op, lds, sl, nl, sr, nr, so, no, cnt);
+                free_mask &= ~(1u << so);
+                free_mask |= (1u << sl) | (1u << sr);
+            }
             sp -= 2;
             stack_slots = (stack_slots & ~(0xFFu << (sp * 4))) | (so << (sp * 4));
             len_l = (len_l & ~(0xFFu << (sp * 4))) | (no << (sp * 4));
             sp++;
         }
+    }
+    // a sub-tree no ray of the wave can hit (inner OP_BOUND): its list is empty
+    __device__ __forceinline__ void push_empty() {
+        uint32_t slot = __builtin_ctz(free_mask);
+        free_mask &= ~(1u << slot);
+        stack_slots = (stack_slots & ~(15u << (sp * 4))) | (slot << (sp * 4));
+        len_l = len_l & ~(15u << (sp * 4));
+        sp++;
     }
     __device__ __forceinline__ uint32_t out_slot() const { return stack_slots & 15u; }
     __device__ __forceinline__ uint32_t out_len() const { return len_l & 15u; }
@@ -475,8 +538,9 @@ __device__ __forceinline__ bool csg_first_hit(Lds &lds, uint32_t slot, uint32_t 
     bool have = false;
     float best = RRT_F32_MAX;
     for (uint32_t e = 0; e < n; e++) {
-        float t = lds.t(slot, e);
-        uint32_t m = lds.m(slot, e);
+        float t;
+        uint32_t m;
+        lds.get(slot, e, t, m);
         if (t < 0.0f) continue;
         if (!(m & META_ENTER)) continue;
         if (t < best) {
@@ -546,7 +610,11 @@ __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, C
     for (uint32_t k = 0; k < S.n_prog; k++) {
         const ProgRec &rec = S.prog[k];
         if ((rec.op & 0xFFu) == OP_BOUND) {
-            if (!__any(bound_hit(rec, rb, o))) k += rec.aux;
+            if (rec.op & PF_FIRST) csg.reset();
+            if (!__any(bound_hit(rec, rb, o))) {
+                k += rec.aux;
+                if (rec.op & PF_CSG) csg.push_empty();  // bound of a sub-tree inside a CSG program
+            }
             continue;
         }
         float t;
@@ -570,7 +638,11 @@ __device__ __forceinline__ bool shadowtrace(const DevScene &S, f3 o, f3 d, float
     for (uint32_t k = 0; k < S.n_prog; k++) {
         const ProgRec &rec = S.prog[k];
         if ((rec.op & 0xFFu) == OP_BOUND) {
-            if (!__any(bound_hit(rec, rb, o))) k += rec.aux;
+            if (rec.op & PF_FIRST) csg.reset();
+            if (!__any(bound_hit(rec, rb, o))) {
+                k += rec.aux;
+                if (rec.op & PF_CSG) csg.push_empty();  // bound of a sub-tree inside a CSG program
+            }
             continue;
         }
         float t;
@@ -610,6 +682,7 @@ __device__ __forceinline__ f3 tex_fetch(const DevScene &S, int32_t id, float u, 
 
 // Material::normal (texture.rs:173-184 through compound_material.rs:104-116)
 __device__ __forceinline__ bool material_normal(const DevScene &S, int32_t material, float u, float v, f3 &out) {
+    if ((uint32_t)material >= S.n_materials) return false;
     const DevMaterial &M = S.materials[material];
     if (M.nm_part < 0) return false;
     const MatPart &P = M.parts[M.nm_part];
@@ -649,11 +722,24 @@ __device__ __forceinline__ void plane_attr(const DevScene &S, uint32_t plane, ui
 }
 
 __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t instr_index, uint32_t sub, float t, HitAttr &h) {
+    // Index guards: a winner record that is out of range means a broken invariant upstream.  Refuse it (the caller
+    // sees material -1 and raises the internal-error bit) rather than fault the GPU on a wild address.
+    h.position = h.normal = mk3(0.0f, 0.0f, 0.0f);
+    h.u = h.v = 0.0f;
+    h.has_tex = false;
+    h.material = -1;
+    if (instr_index >= S.n_prog) return;
     const ProgRec &in = S.prog[instr_index];
     const float PI_F = 3.14159265358979323846f;
     switch (in.op & 0xFFu) {
-        case OP_PLANE: plane_attr(S, in.aux, sub, o, d, t, h); break;
-        case OP_CUBOID: plane_attr(S, in.aux + (sub >> 1), sub & 1u, o, d, t, h); break;
+        case OP_PLANE:
+            if (in.aux >= S.n_plane_cold) return;
+            plane_attr(S, in.aux, sub, o, d, t, h);
+            break;
+        case OP_CUBOID:
+            if (sub >= 12u || in.aux + 6u > S.n_plane_cold) return;
+            plane_attr(S, in.aux + (sub >> 1), sub & 1u, o, d, t, h);
+            break;
         case OP_SPHERE: {  // sphere_object.rs:55-88
             f3 c = mk3(in.p[0], in.p[1], in.p[2]);
             h.material = in.material;
@@ -688,7 +774,9 @@ __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t
             break;
         }
         case OP_MESH: {  // triangle_object.rs:85-160 for the winning triangle only
+            if (in.aux >= S.n_meshes) return;
             const MeshInfo &M = S.meshes[in.aux];
+            if (sub >= M.tri_count) return;
             const TriHot T = S.tris[M.tri_first + sub];
             h.material = M.material;
             f3 n = mk3(T.a_nx.w, T.b_ny.w, T.c_nz.w);

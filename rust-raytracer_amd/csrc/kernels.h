@@ -26,6 +26,7 @@ struct DevPhotonMap {
 
 // error bits of TraceArgs::err (1, 2, 4: dev_shade.h)
 #define RRT_ERR_BIT_QUEUE 8u  // a level queue outgrew the size predicted from the previous frame (internal: retried)
+#define RRT_ERR_BIT_INTERNAL 16u  // a device-side index guard tripped: the kernel refused an out-of-range index
 
 enum StatSlot { ST_NODES = 0, ST_TRIS, ST_SHADOW, ST_GATHERED, ST_QUERIES, ST_CANDIDATES, ST_COUNT };
 

@@ -25,8 +25,7 @@ __device__ __forceinline__ Lds make_lds(uint32_t lds_slots) {
     Lds l;
     l.nthreads = RRT_BLOCK;
     l.tid = threadIdx.x;
-    l.lt = reinterpret_cast<float *>(g_smem);
-    l.lm = reinterpret_cast<uint32_t *>(g_smem) + lds_slots * RRT_LIST_CAP * RRT_BLOCK;
+    l.le = reinterpret_cast<float2 *>(g_smem);
     l.stack = reinterpret_cast<int *>(g_smem);
     return l;
 }
@@ -111,13 +110,19 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
         }
         TraceResult tr;
         trace(S, o, d, lds, cnt, tr);
+        HitAttr h;
+        if (tr.object != 0xFFFFFFFFu) {
+            eval_hit(S, o, d, tr.instr, tr.sub, tr.t, h);
+            if ((uint32_t)h.material >= S.n_materials) {  // index guard of eval_hit tripped
+                cnt.overflow |= RRT_ERR_BIT_INTERNAL;
+                tr.object = 0xFFFFFFFFu;
+            }
+        }
         if (tr.object == 0xFFFFFFFFu) {  // scene.rs:85-90 / photon_scene.rs:311-313
             A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             A.cur.glob[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
             A.cur.object_id[i] = 0xFFFFFFFFu;
         } else {
-            HitAttr h;
-            eval_hit(S, o, d, tr.instr, tr.sub, tr.t, h);
             const DevMaterial &M = S.materials[h.material];
             uint32_t flags = NF_HIT;
             float kr = 0.0f;
@@ -304,6 +309,12 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_batch_trace(BatchTraceArgs A) {
         uint32_t prim = 0;
         if (ok) {
             eval_hit(A.S, o, d, tr.instr, tr.sub, tr.t, h);
+            if ((uint32_t)h.material >= A.S.n_materials) {  // index guard of eval_hit tripped
+                cnt.overflow |= RRT_ERR_BIT_INTERNAL;
+                ok = false;
+            }
+        }
+        if (ok) {
             const ProgRec &in = A.S.prog[tr.instr];
             uint32_t op = in.op & 0xFFu;
             if (op == OP_MESH) {
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_batch_trace(BatchTraceArgs A) {
                 prim = A.S.tri_index[M.tri_first + tr.sub];
             } else if (in.op & PF_CSG) {  // leaf number in post-order
                 uint32_t leaf = 0;
-                for (uint32_t k = tr.instr; !(A.S.prog[k].op & PF_FIRST);) {
+                for (uint32_t k = tr.instr; k > 0 && !(A.S.prog[k].op & PF_FIRST);) {
                     k--;
                     if ((A.S.prog[k].op & 0xFFu) < OP_CSG_UNION) leaf++;
                 }

@@ -80,8 +80,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
     Lds lds;
     lds.nthreads = RRT_BLOCK;
     lds.tid = threadIdx.x;
-    lds.lt = reinterpret_cast<float *>(g_smem_ph);
-    lds.lm = reinterpret_cast<uint32_t *>(g_smem_ph) + A.lds_slots * RRT_LIST_CAP * RRT_BLOCK;
+    lds.le = reinterpret_cast<float2 *>(g_smem_ph);
     lds.stack = reinterpret_cast<int *>(g_smem_ph);
     uint32_t gid = blockIdx.x * RRT_BLOCK + threadIdx.x;
     bool alive = gid < A.count;
@@ -135,6 +134,11 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
         int choice = 0;
         if (alive) {
             eval_hit(S, origin, dir, tr.instr, tr.sub, tr.t, h);
+            if ((uint32_t)h.material >= S.n_materials) {  // index guard of eval_hit tripped
+                err |= RRT_ERR_BIT_INTERNAL;
+                alive = false;
+                h.material = 0;
+            }
             const DevMaterial &M = S.materials[h.material];
             // choose_weighted over [Absorb, Diffuse, Specular, ReflectOrRefract], photon_scene.rs:160-167
             float c1 = M.w[0], c2 = c1 + M.w[1], c3 = c2 + M.w[2], total = c3 + M.w[3];
@@ -158,7 +162,11 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
             for (uint32_t k = 0; k < S.n_prog; k++) {
                 const ProgRec &rec = S.prog[k];
                 if ((rec.op & 0xFFu) == OP_BOUND) {
-                    if (!__any(alive && bound_hit(rec, rb, so))) k += rec.aux;
+                    if (rec.op & PF_FIRST) csg.reset();
+                    if (!__any(alive && bound_hit(rec, rb, so))) {
+                        k += rec.aux;
+                        if (rec.op & PF_CSG) csg.push_empty();
+                    }
                     continue;
                 }
                 if (!(rec.op & PF_CSG)) {
@@ -181,8 +189,9 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
                         bool have = false;
                         float t = 0.0f;
                         if (e < n) {
-                            t = lds.t(slot, e);
-                            have = (lds.m(slot, e) & META_ENTER) && !(t < 0.0f);
+                            uint32_t m;
+                            lds.get(slot, e, t, m);
+                            have = (m & META_ENTER) && !(t < 0.0f);
                         }
                         if (!__any(have)) continue;
                         if (have && sub >= 64) {
@@ -509,6 +518,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         uint32_t err = 0, got[2];
         RRT_HIP(hipMemcpy(&err, s->counters.p + 63, 4, hipMemcpyDeviceToHost));
         RRT_HIP(hipMemcpy(got, counts.p, sizeof(got), hipMemcpyDeviceToHost));
+        if (err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");
         if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
         if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
         if (err & 4u) return fail(RRT_ERR_LIMIT, "more than 63 shadow photons behind one landing");

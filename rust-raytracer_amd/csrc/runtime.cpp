@@ -93,6 +93,59 @@ uint32_t add_plane(Flat &F, f3 point, f3 up, f3 normal, float d, int material) {
     return idx;
 }
 
+// Conservative box for the skip test of dev_trace.h "object bounds".  finite == false: never skipped.
+struct Box {
+    bool finite = false;
+    float lo[3], hi[3];
+    float area() const {
+        float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x * y + y * z + z * x;
+    }
+};
+bool same_box(const Box &a, const Box &b) {
+    if (a.finite != b.finite) return false;
+    for (int k = 0; k < 3; k++)
+        if (a.lo[k] != b.lo[k] || a.hi[k] != b.hi[k]) return false;
+    return true;
+}
+Box bound_of(const HostObject &o) {
+    Box b;
+    switch (o.kind) {
+        case RRT_OBJ_CUBOID: {  // hits must pass the inside test of cuboid_object.rs:107-112
+            const float c[3] = {o.p0.x, o.p0.y, o.p0.z}, sz[3] = {o.p1.x, o.p1.y, o.p1.z};
+            b.finite = true;
+            for (int a = 0; a < 3; a++) {
+                b.lo[a] = c[a] - 0.0001f;
+                b.hi[a] = c[a] + sz[a] + 0.0001f;
+                if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) b.finite = false;
+            }
+            break;
+        }
+        case RRT_OBJ_CSG: {
+            Box l = bound_of(*o.left), r = bound_of(*o.right);
+            if (o.csg_mode == RRT_CSG_UNION) {  // no hits unless one operand has hits
+                if (l.finite && r.finite) {
+                    b.finite = true;
+                    for (int a = 0; a < 3; a++) {
+                        b.lo[a] = std::min(l.lo[a], r.lo[a]);
+                        b.hi[a] = std::max(l.hi[a], r.hi[a]);
+                    }
+                }
+            } else if (o.csg_mode == RRT_CSG_INTERSECTION) {  // no hits unless BOTH operands have hits: either box will do
+                if (l.finite && r.finite)
+                    b = l.area() <= r.area() ? l : r;
+                else
+                    b = l.finite ? l : r;
+            } else {  // difference: no hits unless the left operand has hits
+                b = l;
+            }
+            break;
+        }
+        default: break;  // planes and quadrics: unbounded or not worth a test; meshes: their BVH root does this
+    }
+    return b;
+}
+
 ProgRec &push_rec(Flat &F, uint32_t op, int material, uint32_t aux) {
     ProgRec r;
     memset(&r, 0, sizeof(r));
@@ -103,7 +156,24 @@ ProgRec &push_rec(Flat &F, uint32_t op, int material, uint32_t aux) {
     return F.prog.back();
 }
 
-void emit(Flat &F, const HostObject &o) {
+// OP_BOUND record for `bb`; the caller fills aux (records to skip) once they are emitted
+int push_bound(Flat &F, const Box &bb, uint32_t flags) {
+    int at = (int)F.prog.size();
+    ProgRec &r = push_rec(F, OP_BOUND | flags, -1, 0);
+    for (int a = 0; a < 3; a++) {
+        // absolute pad: rounding of o + d*t at the box's own coordinate magnitude, with a wide margin
+        float mag = std::max(std::fabs(bb.lo[a]), std::fabs(bb.hi[a])) + std::fabs(bb.hi[a] - bb.lo[a]);
+        float pad = 1e-4f * mag + 1e-4f;
+        r.p[a] = bb.lo[a] - pad;
+        r.p[3 + a] = bb.hi[a] + pad;
+    }
+    r.p[6] = 3.2e-5f;  // pad per unit of |origin|: rounding of o + d*t for far origins (error <~ 1e-6 |o|)
+    return at;
+}
+
+static bool g_bounds_enabled = true;
+
+void emit(Flat &F, const HostObject &o, const Box &enclosing) {
     switch (o.kind) {
         case RRT_OBJ_PLANE: {
             uint32_t idx = add_plane(F, o.p0, o.p1, o.p2, o.d, o.material);
@@ -184,59 +254,21 @@ void emit(Flat &F, const HostObject &o) {
             F.meshes.push_back(mi);
             break;
         }
-        case RRT_OBJ_CSG:
-            emit(F, *o.left);
-            emit(F, *o.right);
+        case RRT_OBJ_CSG: {
+            // sub-trees that are CSG nodes themselves get their own bound when it is tighter than the enclosing one
+            const HostObject *kids[2] = {o.left.get(), o.right.get()};
+            for (const HostObject *kid : kids) {
+                Box kb = bound_of(*kid);
+                bool own = g_bounds_enabled && kid->kind == RRT_OBJ_CSG && kb.finite && !same_box(kb, enclosing);
+                int at = own ? push_bound(F, kb, PF_CSG) : -1;
+                uint32_t first = (uint32_t)F.prog.size();
+                emit(F, *kid, own ? kb : enclosing);
+                if (own) F.prog[at].aux = (uint32_t)F.prog.size() - first;
+            }
             push_rec(F, (uint32_t)(OP_CSG_UNION + o.csg_mode), -1, 0);
             break;
-    }
-}
-
-// Conservative box for the skip test of dev_trace.h "object bounds".  finite == false: never skipped.
-struct Box {
-    bool finite = false;
-    float lo[3], hi[3];
-    float area() const {
-        float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
-        return x * y + y * z + z * x;
-    }
-};
-Box bound_of(const HostObject &o) {
-    Box b;
-    switch (o.kind) {
-        case RRT_OBJ_CUBOID: {  // hits must pass the inside test of cuboid_object.rs:107-112
-            const float c[3] = {o.p0.x, o.p0.y, o.p0.z}, sz[3] = {o.p1.x, o.p1.y, o.p1.z};
-            b.finite = true;
-            for (int a = 0; a < 3; a++) {
-                b.lo[a] = c[a] - 0.0001f;
-                b.hi[a] = c[a] + sz[a] + 0.0001f;
-                if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) b.finite = false;
-            }
-            break;
         }
-        case RRT_OBJ_CSG: {
-            Box l = bound_of(*o.left), r = bound_of(*o.right);
-            if (o.csg_mode == RRT_CSG_UNION) {  // no hits unless one operand has hits
-                if (l.finite && r.finite) {
-                    b.finite = true;
-                    for (int a = 0; a < 3; a++) {
-                        b.lo[a] = std::min(l.lo[a], r.lo[a]);
-                        b.hi[a] = std::max(l.hi[a], r.hi[a]);
-                    }
-                }
-            } else if (o.csg_mode == RRT_CSG_INTERSECTION) {  // no hits unless BOTH operands have hits: either box will do
-                if (l.finite && r.finite)
-                    b = l.area() <= r.area() ? l : r;
-                else
-                    b = l.finite ? l : r;
-            } else {  // difference: no hits unless the left operand has hits
-                b = l;
-            }
-            break;
-        }
-        default: break;  // planes and quadrics: unbounded or not worth a test; meshes: their BVH root does this
     }
-    return b;
 }
 
 int flatten_materials(rrt_scene *s, std::vector<DevMaterial> &out, bool &reflective) {
@@ -296,31 +328,21 @@ int flatten_materials(rrt_scene *s, std::vector<DevMaterial> &out, bool &reflect
 }  // namespace
 
 int flatten_scene(rrt_scene *s) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(RRT_ERR_DEVICE, "no HIP device: librrt has no CPU fallback");
     Flat F;
+    g_bounds_enabled = getenv("RRT_NO_BOUNDS") == nullptr;  // debugging aid: the reference's plain all-objects loop
     uint32_t max_stack = 0;
     bool has_csg = false, has_bounds = false;
     for (size_t oi = 0; oi < s->objects.size(); oi++) {
         const HostObject &ho = *s->objects[oi];
         Box bb = bound_of(ho);
+        if (!g_bounds_enabled) bb.finite = false;
         int bound_rec = -1;
-        if (bb.finite && !getenv("RRT_NO_BOUNDS")) {
-            bound_rec = (int)F.prog.size();
-            ProgRec &r = push_rec(F, OP_BOUND, -1, 0);
-            for (int a = 0; a < 3; a++) {
-                // absolute pad: rounding of o + d*t at the box's own coordinate magnitude, with a wide margin
-                float mag = std::max(std::fabs(bb.lo[a]), std::fabs(bb.hi[a])) + std::fabs(bb.hi[a] - bb.lo[a]);
-                float pad = 1e-4f * mag + 1e-4f;
-                r.p[a] = bb.lo[a] - pad;
-                r.p[3 + a] = bb.hi[a] + pad;
-            }
-            r.p[6] = 3.2e-5f;  // pad per unit of |origin|: rounding of o + d*t for far origins (error <~ 1e-6 |o|)
+        if (bb.finite) {
+            bound_rec = push_bound(F, bb, 0);
             has_bounds = true;
         }
         uint32_t first = (uint32_t)F.prog.size();
-        emit(F, ho);
+        emit(F, ho, bb);
         uint32_t count = (uint32_t)F.prog.size() - first;
         if (bound_rec >= 0) F.prog[bound_rec].aux = count;
         for (uint32_t k = 0; k < count; k++) F.prog[first + k].object = (uint32_t)oi;
@@ -330,8 +352,10 @@ int flatten_scene(rrt_scene *s) {
             has_csg = true;
             uint32_t sp = 0;
             for (uint32_t k = 0; k < count; k++) {
-                F.prog[first + k].op |= PF_CSG;
-                if ((F.prog[first + k].op & 0xFFu) < OP_CSG_UNION)
+                ProgRec &r = F.prog[first + k];
+                r.op |= PF_CSG;
+                if ((r.op & 0xFFu) == OP_BOUND) continue;
+                if ((r.op & 0xFFu) < OP_CSG_UNION)
                     sp++;
                 else
                     sp--;
@@ -339,6 +363,37 @@ int flatten_scene(rrt_scene *s) {
             }
         }
     }
+    if (getenv("RRT_DUMP_PROGRAM")) {  // debugging aid: the record stream, without touching the device
+        static const char *names[] = {"plane", "sphere", "cuboid", "quadric", "mesh", "union", "intersection", "difference", "bound"};
+        for (size_t k = 0; k < F.prog.size(); k++) {
+            const ProgRec &r = F.prog[k];
+            fprintf(stderr, "%3zu obj %2u %-12s%s%s%s aux %u\n", k, r.object, names[r.op & 0xFFu], (r.op & PF_FIRST) ? " FIRST" : "",
+                    (r.op & PF_LAST) ? " LAST" : "", (r.op & PF_CSG) ? " CSG" : "", r.aux);
+        }
+        fprintf(stderr, "max_stack %u\n", max_stack);
+    }
+    if (const char *path = getenv("RRT_DUMP_SCENE")) {  // debugging aid: geometry arrays for tools/cpu_emu (no device needed)
+        if (FILE *f = fopen(path, "wb")) {
+            auto put = [&](const void *p, size_t elem, size_t n) {
+                uint64_t hdr[2] = {elem, n};
+                fwrite(hdr, sizeof(hdr), 1, f);
+                if (n) fwrite(p, elem, n, f);
+            };
+            uint32_t misc[4] = {has_csg ? max_stack + 1 : 0u, F.bvh_depth ? F.bvh_depth + 1 : 0u, has_bounds ? 1u : 0u, has_csg ? 1u : 0u};
+            put(misc, 4, 4);
+            put(F.prog.data(), sizeof(ProgRec), F.prog.size());
+            put(F.plane_cold.data(), sizeof(PlaneCold), F.plane_cold.size());
+            put(F.meshes.data(), sizeof(MeshInfo), F.meshes.size());
+            put(F.tris.data(), sizeof(TriHot), F.tris.size());
+            put(F.tri_index.data(), 4, F.tri_index.size());
+            put(F.tri_normals.data(), 4, F.tri_normals.size());
+            put(F.nodes.data(), sizeof(BvhNode), F.nodes.size());
+            fclose(f);
+        }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(RRT_ERR_DEVICE, "no HIP device: librrt has no CPU fallback");
     // the hit lists keep the record index of each hit in 16 bits (mk_meta in dev_trace.h)
     if (has_csg && F.prog.size() > 0xFFFF) return fail(RRT_ERR_LIMIT, "scene with CSG objects has more than 65535 primitive records");
     DeviceScene &D = s->dev;
@@ -346,7 +401,7 @@ int flatten_scene(rrt_scene *s) {
     if (D.lds_slots > 8) return fail(RRT_ERR_LIMIT, "CSG tree needs more than 7 live hit lists");
     D.bvh_stack = F.bvh_depth ? F.bvh_depth + 1 : 0;
     size_t list_bytes = (size_t)D.lds_slots * 6 /* HitVec capacity */ * 256 * 8;
-    size_t stack_bytes = (size_t)D.bvh_stack * 256 * 4;
+    size_t stack_bytes = (size_t)((D.bvh_stack + 1) / 2) * 256 * 8;  // two stack words per 8-byte column element (dev_trace.h Lds)
     D.lds_bytes = std::max(list_bytes, stack_bytes);
     if (D.lds_bytes > 160 * 1024) return fail(RRT_ERR_LIMIT, "per-block LDS need exceeds 160 KiB (BVH too deep)");
     D.flops_per_trace = F.flops;
@@ -413,6 +468,9 @@ int flatten_scene(rrt_scene *s) {
     V.n_lights = (uint32_t)lights.size();
     V.has_csg = has_csg ? 1 : 0;
     V.has_bounds = has_bounds ? 1 : 0;
+    V.n_plane_cold = (uint32_t)F.plane_cold.size();
+    V.n_meshes = (uint32_t)F.meshes.size();
+    V.n_materials = (uint32_t)mats.size();
     V.plane_cold = D.plane_cold.p;
     V.meshes = D.meshes.p;
     V.tris = D.tris.p;
@@ -601,6 +659,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     R.ms_trace_kernels = ms_trace;
     R.ms_total = ms_total;
     uint32_t err = s->host_pinned[0];
+    if (err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");
     if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
     if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
     return RRT_OK;
@@ -1006,6 +1065,7 @@ static int batch_common(rrt_scene *s, const float *origins, const float *directi
     RRT_HIP(hipMemcpy(st, s->stats_dev.p, sizeof(st), hipMemcpyDeviceToHost));
     s->stats.bvh_nodes_visited = st[ST_NODES];
     s->stats.bvh_tris_tested = st[ST_TRIS];
+    if (err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");
     if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
     if (shadow) {
         RRT_HIP(hipMemcpy(occluded, d_occ.p, n, hipMemcpyDeviceToHost));

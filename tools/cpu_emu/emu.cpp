@@ -1,0 +1,159 @@
+// Runs librrt's DEVICE trace code on the CPU in waves of 64 lanes (one thread per lane; __any is a real collective
+// over the lanes that have not left the current call, so a lane sequence that is not wave-uniform deadlocks or
+// is reported), under AddressSanitizer, on a scene dumped by
+// RRT_DUMP_SCENE=<file> (runtime.cpp) and rays from a raw f32 file [n][6]; writes object / distance per ray.
+// Used to find indexing faults before a kernel goes to the GPU box.  Build: tools/cpu_emu/build.sh
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+// every LDS access must stay inside the block's allocation (g_lds_elems 8-byte elements, the host's lds_bytes / 8)
+// and inside the accessing lane's own column: element index % block size == lane
+static size_t g_lds_elems = 0;
+#define RRT_LDS_CHECK(lds, elem)                                                                                         \
+    do {                                                                                                                 \
+        size_t e_ = (elem);                                                                                              \
+        if (e_ >= g_lds_elems || e_ % (lds).nthreads != (lds).tid) {                                                    \
+            fprintf(stderr, "LDS CHECK FAILED: element %zu (allocation %zu), lane %u of %u\n", e_, g_lds_elems, (lds).tid, (lds).nthreads); \
+            abort();                                                                                                     \
+        }                                                                                                                \
+    } while (0)
+#include "dev_trace.h"
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+using namespace rrt;
+
+struct Wave {
+    std::mutex m;
+    std::condition_variable cv;
+    int active = 0, arrived = 0;
+    bool acc = false, result = false;
+    uint64_t gen = 0;
+    void complete() {
+        result = acc;
+        acc = false;
+        arrived = 0;
+        gen++;
+        cv.notify_all();
+    }
+    bool any(bool x) {
+        std::unique_lock<std::mutex> l(m);
+        acc |= x;
+        if (++arrived == active) {
+            complete();
+            return result;
+        }
+        uint64_t g = gen;
+        if (!cv.wait_for(l, std::chrono::seconds(20), [&] { return gen != g; })) {
+            fprintf(stderr, "DEADLOCK: lanes disagree on the sequence of wave collectives\n");
+            abort();
+        }
+        return result;
+    }
+    void leave() {  // lane returns from the call
+        std::unique_lock<std::mutex> l(m);
+        active--;
+        if (active > 0 && arrived == active) complete();
+    }
+    void join_all(int n) {
+        std::unique_lock<std::mutex> l(m);
+        active = n;
+        arrived = 0;
+        acc = false;
+    }
+};
+static thread_local Wave *tl_wave = nullptr;
+bool __any(bool x) { return tl_wave->any(x); }
+template <class T> static std::vector<T> get(FILE *f) {
+    uint64_t hdr[2];
+    if (fread(hdr, sizeof(hdr), 1, f) != 1) { fprintf(stderr, "short file\n"); exit(2); }
+    if (hdr[0] != sizeof(T)) { fprintf(stderr, "element size %llu != %zu\n", (unsigned long long)hdr[0], sizeof(T)); exit(2); }
+    std::vector<T> v(hdr[1]);
+    if (hdr[1] && fread(v.data(), sizeof(T), hdr[1], f) != hdr[1]) { fprintf(stderr, "short array\n"); exit(2); }
+    return v;
+}
+int main(int argc, char **argv) {
+    if (argc < 4) { fprintf(stderr, "usage: emu scene.bin rays.f32 out.bin\n"); return 2; }
+    FILE *f = fopen(argv[1], "rb");
+    auto misc = get<uint32_t>(f);
+    auto prog = get<ProgRec>(f);
+    auto plane_cold = get<PlaneCold>(f);
+    auto meshes = get<MeshInfo>(f);
+    auto tris = get<TriHot>(f);
+    auto tri_index = get<uint32_t>(f);
+    auto tri_normals = get<float>(f);
+    auto nodes = get<BvhNode>(f);
+    fclose(f);
+    DevScene S;
+    memset(&S, 0, sizeof(S));
+    S.prog = prog.data(); S.n_prog = (uint32_t)prog.size(); S.has_bounds = misc[2]; S.has_csg = misc[3];
+    S.plane_cold = plane_cold.data(); S.meshes = meshes.data(); S.tris = tris.data(); S.tri_index = tri_index.data();
+    S.tri_normals = tri_normals.data(); S.nodes = nodes.data();
+    FILE *r = fopen(argv[2], "rb");
+    fseek(r, 0, SEEK_END); long bytes = ftell(r); fseek(r, 0, SEEK_SET);
+    std::vector<float> rays(bytes / 4);
+    if (fread(rays.data(), 4, rays.size(), r) != rays.size()) return 2;
+    fclose(r);
+    size_t n = rays.size() / 6;
+    std::vector<uint32_t> results(n * 4);
+    uint32_t overflow = 0;
+    std::mutex om;
+    const int W = 64;
+    for (size_t base = 0; base < n; base += W) {
+        int lanes = (int)std::min<size_t>(W, n - base);
+        // exact-size heap arrays: ASan flags any entry or slot index out of range
+        // ONE buffer, laid out and sized as runtime.cpp does for a 256-thread block (lists and BVH stack alias);
+        // the wave emulated here plays lanes 64..127 of that block.  Filled with garbage, as on the device.
+        const uint32_t BLOCK = 256;
+        size_t list_bytes = (size_t)misc[0] * 6 * BLOCK * 8, stack_bytes = (size_t)((misc[1] + 1) / 2) * BLOCK * 8;
+        g_lds_elems = std::max(list_bytes, stack_bytes) / 8;
+        std::vector<float2> lists(g_lds_elems, float2{1.5f, __uint_as_float(0xFFFFFFFFu)});
+        Wave wave, sync;
+        std::vector<std::thread> th;
+        for (int phase = 0; phase < 2; phase++) {
+            wave.join_all(lanes);
+            th.clear();
+            for (int lane = 0; lane < lanes; lane++)
+                th.emplace_back([&, lane, phase] {
+                    tl_wave = &wave;
+                    size_t i = base + lane;
+                    Lds lds; lds.le = lists.data(); lds.stack = reinterpret_cast<int *>(lists.data()); lds.nthreads = BLOCK; lds.tid = 64u + (uint32_t)lane;
+                    Counters cnt = {0, 0, 0, 0};
+                    f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+                    if (phase == 0) {
+                        TraceResult tr;
+                        trace(S, o, d, lds, cnt, tr);
+                        results[i * 4] = tr.object;
+                        results[i * 4 + 1] = __float_as_uint(tr.object == 0xFFFFFFFFu ? 0.0f : tr.t);
+                        uint32_t prim = 0;  // as k_batch_trace computes it
+                        if (tr.object != 0xFFFFFFFFu) {
+                            const ProgRec &in = S.prog[tr.instr];
+                            uint32_t op = in.op & 0xFFu;
+                            if (op == OP_MESH) {
+                                prim = S.tri_index[S.meshes[in.aux].tri_first + tr.sub];
+                            } else if (in.op & PF_CSG) {
+                                for (uint32_t k = tr.instr; !(S.prog[k].op & PF_FIRST);) {
+                                    k--;
+                                    if ((S.prog[k].op & 0xFFu) < OP_CSG_UNION) prim++;
+                                }
+                            } else if (op == OP_CUBOID) {
+                                prim = tr.sub;
+                                if (in.aux + (tr.sub >> 1) >= plane_cold.size()) abort();
+                            }
+                        }
+                        results[i * 4 + 2] = prim;
+                    } else {
+                        results[i * 4 + 3] = shadowtrace(S, o, d, 6.0f, lds, cnt) ? 1u : 0u;
+                    }
+                    wave.leave();
+                    if (cnt.overflow) { std::lock_guard<std::mutex> g(om); overflow |= cnt.overflow; }
+                });
+            for (auto &t : th) t.join();
+        }
+    }
+    FILE *out = fopen(argv[3], "wb");
+    fwrite(results.data(), 4, results.size(), out);
+    fclose(out);
+    fprintf(stderr, "%zu rays, overflow %u\n", n, overflow);
+    return 0;
+}
