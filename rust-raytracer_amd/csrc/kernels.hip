@@ -81,7 +81,7 @@ __device__ __forceinline__ uint32_t node_pixel(uint32_t g, uint32_t width, uint3
 }
 
 #ifndef RRT_MIN_WAVES
-#define RRT_MIN_WAVES 1
+#define RRT_MIN_WAVES 3
 #endif
 // MODE is a template parameter so that the raytracing-mode instance does not carry the registers of the photon
 // gather and vice versa (occupancy is VGPR-limited here).
@@ -292,7 +292,10 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
 }
 
 // ---- batched Environment::trace / Scene::shadowtrace for the C ABI's test entry points ----
-__global__ __launch_bounds__(RRT_BLOCK) void k_batch_trace(BatchTraceArgs A) {
+#ifndef RRT_BATCH_WAVES
+#define RRT_BATCH_WAVES 1
+#endif
+__global__ __launch_bounds__(RRT_BLOCK, RRT_BATCH_WAVES) void k_batch_trace(BatchTraceArgs A) {
     Lds lds = make_lds(A.lds_slots);
     uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
     Counters cnt = {0, 0, 0, 0};
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_batch_trace(BatchTraceArgs A) {
     flush_counters(cnt, 0, 0, 0, A.stats, A.err);
 }
 
-__global__ __launch_bounds__(RRT_BLOCK) void k_batch_shadow(BatchTraceArgs A) {
+__global__ __launch_bounds__(RRT_BLOCK, RRT_BATCH_WAVES) void k_batch_shadow(BatchTraceArgs A) {
     Lds lds = make_lds(A.lds_slots);
     uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
     Counters cnt = {0, 0, 0, 0};
