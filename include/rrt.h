@@ -53,7 +53,11 @@ typedef struct rrt_params {
     uint32_t max_vueon_depth;           /* reference: unbounded (photon_scene.rs:329-352); deeper
                                            vueons return black here (default 12)                    */
     uint32_t chunk_pixels;              /* pixels per wavefront-queue chunk (0 = default 1<<22)     */
-    uint32_t reserved[9];
+    uint32_t render_streams;            /* HIP streams the chunks of a frame are spread over (0 or 1 =
+                                           the caller's stream only, the default; at most 8).  Measured
+                                           on MI355X: 2 / 4 / 8 streams are 7 / 17 / 70 % slower on the
+                                           1080p CSG scene, so this is off by default      */
+    uint32_t reserved[8];
 } rrt_params;
 
 /* ---- materials (src/materials) ------------------------------------------------------ */
@@ -151,7 +155,9 @@ typedef struct rrt_stats {
     double ms_photon_build;
     uint64_t flops_algorithmic;  /* SURVEY.md 8d count: per-primitive flops x tests + 27/box + 61/triangle */
     uint64_t flops_per_trace;    /* analytic-primitive flops one trace() of this scene costs           */
-    uint64_t reserved[6];
+    uint64_t frames_repeated;    /* render calls since rrt_pre_render that were run twice because a level
+                                    queue outgrew the size predicted from the previous frame */
+    uint64_t reserved[5];
 } rrt_stats;
 
 /* ---- builder vtable --------------------------------------------------------------------

@@ -20,7 +20,8 @@ class Params(C.Structure):
         ("max_photon_bounces", C.c_uint32),
         ("max_vueon_depth", C.c_uint32),
         ("chunk_pixels", C.c_uint32),
-        ("reserved", C.c_uint32 * 9),
+        ("render_streams", C.c_uint32),
+        ("reserved", C.c_uint32 * 8),
     ]
 
 
@@ -96,7 +97,8 @@ class Stats(C.Structure):
         ("ms_photon_build", C.c_double),
         ("flops_algorithmic", C.c_uint64),
         ("flops_per_trace", C.c_uint64),
-        ("reserved", C.c_uint64 * 6),
+        ("frames_repeated", C.c_uint64),
+        ("reserved", C.c_uint64 * 5),
     ]
 
     def as_dict(self):

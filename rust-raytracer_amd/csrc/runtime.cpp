@@ -11,6 +11,13 @@ using namespace rrt;
 rrt_scene::~rrt_scene() {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (host_pinned) (void)hipHostFree(host_pinned);
+    for (auto &L : lanes) {
+        if (L->stream) (void)hipStreamDestroy(L->stream);
+        if (L->ev_trace0) (void)hipEventDestroy(L->ev_trace0);
+        if (L->ev_trace1) (void)hipEventDestroy(L->ev_trace1);
+        if (L->ev_done) (void)hipEventDestroy(L->ev_done);
+        if (L->host_pinned) (void)hipHostFree(L->host_pinned);
+    }
 }
 
 namespace rrt {
@@ -499,13 +506,65 @@ int ensure_workspace(rrt_scene *s) {
     return RRT_OK;
 }
 
-// The render loop: one chunk of pixels at a time, one queue per recursion level.
-// One frame (or ray batch) through the level queues.
+// ---- the render loop ------------------------------------------------------------------------------
+// A frame (or ray batch) is cut into chunks; each chunk goes through one queue per recursion level.
 //
-// The size of level k+1 is only known once level k has run.  The first frame of a given size finds the sizes out level
-// by level (one 4-byte readback + stream sync per level).  Later frames launch every level for the sizes the previous
-// frame had (+12.5 % + 4096) without waiting, read all counters back once at the end, and fall back to the
-// level-by-level path if a queue outgrew its prediction (RRT_ERR_BIT_QUEUE; nothing is written past a launch's reach).
+// Level sizes.  The size of level k+1 is only known once level k has run.  The first frame of a given size finds the
+// sizes out level by level (a 4-byte readback + stream sync per level).  Later frames launch every level for the sizes
+// the previous frame had (+12.5 % + 4096) without waiting, read all counters back once at the end, and fall back to
+// the level-by-level path if a queue outgrew its prediction (RRT_ERR_BIT_QUEUE; nothing is written past a launch's
+// reach).
+//
+// Lanes.  The deep levels of a chunk hold few rays: their launches cannot fill the GPU and cost one wave's latency
+// each.  Chunks can be spread over `render_streams` lanes (own queues, counters and stream) so that the deep levels of
+// one chunk may run beside the wide shallow levels of another.  On MI355X this measured SLOWER (the smaller launches
+// pay the per-level latency four times and the queues overlap little), so one lane is the default.
+namespace {
+
+int ensure_lanes(rrt_scene *s, uint32_t n) {
+    while (s->lanes.size() < n) {
+        s->lanes.emplace_back(new RenderLane());
+        RenderLane &L = *s->lanes.back();
+        int rc;
+        if ((rc = L.counters.ensure(64))) return rc;
+        RRT_HIP(hipHostMalloc((void **)&L.host_pinned, 64 * sizeof(uint32_t)));
+        if (s->lanes.size() > 1) RRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        RRT_HIP(hipEventCreate(&L.ev_trace0));
+        RRT_HIP(hipEventCreate(&L.ev_trace1));
+        RRT_HIP(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+    }
+    return RRT_OK;
+}
+
+struct ChunkPlan {
+    uint32_t base, n;
+    std::vector<uint32_t> counts;  // rays per level, filled in when known
+};
+
+void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, uint32_t base, uint32_t depth_cap,
+               RenderLane &L, float *rgb_dev, float *depth_dev, uint32_t *id_dev) {
+    DeviceScene &D = s->dev;
+    memset(&A, 0, sizeof(A));
+    A.S = D.view;
+    if (cam) A.cam = *cam;
+    A.maps[0] = s->index[0].view();
+    A.maps[1] = s->index[1].view();
+    A.max_depth = depth_cap;
+    A.mode = (uint32_t)s->mode;
+    A.y0 = y0;
+    A.pixel_base = base;
+    A.band_rows = cam && cam->width ? n_pixels / cam->width : 0;
+    A.lds_slots = D.lds_slots;
+    A.gather_half_width = s->params.gather_half_width;
+    A.err = L.counters.p + 63;
+    A.stats = s->stats_dev.p;
+    A.out_rgb = rgb_dev;
+    A.out_depth = depth_dev;
+    A.out_id = id_dev;
+}
+
+}  // namespace
+
 static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
                             const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream,
                             bool allow_predicted, bool &retry) {
@@ -515,133 +574,180 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     const uint32_t depth_cap = s->mode == RRT_MODE_SCENE ? s->params.max_depth : s->params.max_vueon_depth;
     const uint32_t n_levels = D.reflective ? depth_cap + 1 : 1;
     if (n_levels + 2 > 60) return fail(RRT_ERR_LIMIT, "recursion depth above 57");
-    if (s->levels.size() < n_levels + 1) s->levels.resize(n_levels + 1);
-    uint32_t chunk = s->params.chunk_pixels ? s->params.chunk_pixels : (1u << 22);
     int rc;
-    uint32_t *err_dev = s->counters.p + 63;
-    RRT_HIP(hipMemsetAsync(s->counters.p, 0, 64 * sizeof(uint32_t), stream));
+    uint32_t want_lanes = s->params.render_streams ? std::min(s->params.render_streams, 8u) : 1u;
+    if (n_levels == 1) want_lanes = 1;  // no deep levels to hide
+    uint32_t chunk = s->params.chunk_pixels ? s->params.chunk_pixels : (1u << 22);
+    if (want_lanes > 1 && n_pixels >= (1u << 18)) {  // big enough to be worth cutting: one chunk per lane, whole waves
+        uint32_t per_lane = (n_pixels + want_lanes - 1) / want_lanes;
+        per_lane = (per_lane + 255u) & ~255u;
+        chunk = std::min(chunk, per_lane);
+    } else {
+        want_lanes = 1;
+    }
+    if ((rc = ensure_lanes(s, want_lanes))) return rc;
+    for (uint32_t j = 0; j < want_lanes; j++)
+        if (s->lanes[j]->levels.size() < n_levels + 1) s->lanes[j]->levels.resize(n_levels + 1);
+
     RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, ST_COUNT * sizeof(unsigned long long), stream));
     RRT_HIP(hipEventRecord(s->events[0], stream));
     uint64_t secondary = 0;
     float ms_trace = 0.0f;
-    std::vector<uint32_t> &pred = s->level_prediction;  // [0] = chunk size it was measured on, [1 + k] = size of level k
-    for (uint32_t base = 0; base < n_pixels; base += chunk) {
-        uint32_t n = std::min(chunk, n_pixels - base);
-        std::vector<uint32_t> counts(n_levels + 1, 0), caps(n_levels + 1, 0);
-        counts[0] = caps[0] = n;
-        const bool predicted = allow_predicted && n_levels > 1 && pred.size() == n_levels + 2 && pred[0] == n;
-        if ((rc = s->levels[0].ensure(n, n_lights, cam == nullptr))) return rc;
-        if (!cam) launch_load_rays(origins_dev + (size_t)base * 3, directions_dev + (size_t)base * 3, n, s->levels[0].view(), stream);
-        TraceArgs A;
-        memset(&A, 0, sizeof(A));
-        A.S = D.view;
-        if (cam) A.cam = *cam;
-        A.maps[0] = s->index[0].view();
-        A.maps[1] = s->index[1].view();
-        A.max_depth = depth_cap;
-        A.mode = (uint32_t)s->mode;
-        A.y0 = y0;
-        A.pixel_base = base;
-        A.band_rows = cam && cam->width ? n_pixels / cam->width : 0;
-        A.lds_slots = D.lds_slots;
-        A.gather_half_width = s->params.gather_half_width;
-        A.err = err_dev;
-        A.stats = s->stats_dev.p;
-        A.out_rgb = rgb_dev;
-        A.out_depth = depth_dev;
-        A.out_id = id_dev;
-        uint32_t last = 0;
-        RRT_HIP(hipMemsetAsync(s->counters.p, 0, 60 * sizeof(uint32_t), stream));
+    uint32_t err = 0;
+
+    for (uint32_t round_base = 0; round_base < n_pixels;) {
+        // the chunks of this round, one per lane
+        std::vector<ChunkPlan> plan;
+        for (uint32_t j = 0; j < want_lanes && round_base < n_pixels; j++) {
+            ChunkPlan c;
+            c.base = round_base;
+            c.n = std::min(chunk, n_pixels - round_base);
+            c.counts.assign(n_levels + 1, 0);
+            c.counts[0] = c.n;
+            plan.push_back(c);
+            round_base += c.n;
+        }
+        bool predicted = allow_predicted && n_levels > 1;
+        for (size_t j = 0; j < plan.size(); j++) {
+            const std::vector<uint32_t> &pred = s->lanes[j]->prediction;
+            if (!(pred.size() == n_levels + 2 && pred[0] == plan[j].n)) predicted = false;
+        }
         if (predicted) {
-            for (uint32_t k = 1; k < n_levels; k++) {
-                uint64_t want = (uint64_t)pred[1 + k] + pred[1 + k] / 8 + 4096;
-                caps[k] = (uint32_t)std::min<uint64_t>(want, 2ull * caps[k - 1]);
-                if ((rc = s->levels[k].ensure(caps[k], n_lights, true))) return rc;
+            if (plan.size() > 1) {  // fork: the other lanes start after what the caller's stream holds so far
+                RRT_HIP(hipEventRecord(s->events[2], stream));
+                for (size_t j = 1; j < plan.size(); j++) RRT_HIP(hipStreamWaitEvent(s->lanes[j]->stream, s->events[2], 0));
             }
-            if ((rc = s->levels[n_levels].ensure(1, n_lights, true))) return rc;
-            RRT_HIP(hipEventRecord(s->events[2], stream));
-            for (uint32_t k = 0; k < n_levels; k++) {
-                A.cur = s->levels[k].view();
-                A.next = s->levels[k + 1].view();
-                A.count = caps[k];
-                A.count_ptr = k ? s->counters.p + k : nullptr;
-                A.next_limit = caps[k + 1];
-                A.level = k;
-                A.next_count = s->counters.p + (k + 1);
-                launch_trace_shade(A, D.lds_bytes, stream);
+            for (size_t j = 0; j < plan.size(); j++) {
+                RenderLane &L = *s->lanes[j];
+                hipStream_t st = j == 0 ? stream : L.stream;
+                const std::vector<uint32_t> &pred = L.prediction;
+                std::vector<uint32_t> caps(n_levels + 1, 0);
+                caps[0] = plan[j].n;
+                if ((rc = L.levels[0].ensure(plan[j].n, n_lights, cam == nullptr))) return rc;
+                for (uint32_t k = 1; k < n_levels; k++) {
+                    uint64_t want = (uint64_t)pred[1 + k] + pred[1 + k] / 8 + 4096;
+                    caps[k] = (uint32_t)std::min<uint64_t>(want, 2ull * caps[k - 1]);
+                    if ((rc = L.levels[k].ensure(caps[k], n_lights, true))) return rc;
+                }
+                if ((rc = L.levels[n_levels].ensure(1, n_lights, true))) return rc;
+                RRT_HIP(hipMemsetAsync(L.counters.p, 0, 64 * sizeof(uint32_t), st));
+                if (!cam)
+                    launch_load_rays(origins_dev + (size_t)plan[j].base * 3, directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), st);
+                TraceArgs A;
+                fill_args(s, A, cam, y0, n_pixels, plan[j].base, depth_cap, L, rgb_dev, depth_dev, id_dev);
+                RRT_HIP(hipEventRecord(L.ev_trace0, st));
+                for (uint32_t k = 0; k < n_levels; k++) {
+                    A.cur = L.levels[k].view();
+                    A.next = L.levels[k + 1].view();
+                    A.count = caps[k];
+                    A.count_ptr = k ? L.counters.p + k : nullptr;
+                    A.next_limit = caps[k + 1];
+                    A.level = k;
+                    A.next_count = L.counters.p + (k + 1);
+                    launch_trace_shade(A, D.lds_bytes, st);
+                }
+                RRT_HIP(hipEventRecord(L.ev_trace1, st));
+                for (int k = (int)n_levels - 1; k >= 0; k--) {
+                    A.cur = L.levels[k].view();
+                    A.next = L.levels[k + 1].view();
+                    A.count = caps[k];
+                    A.count_ptr = k ? L.counters.p + k : nullptr;
+                    A.level = (uint32_t)k;
+                    launch_combine(A, st);
+                }
+                RRT_HIP(hipMemcpyAsync(L.host_pinned, L.counters.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                if (j > 0) {  // join
+                    RRT_HIP(hipEventRecord(L.ev_done, st));
+                    RRT_HIP(hipStreamWaitEvent(stream, L.ev_done, 0));
+                }
             }
-            RRT_HIP(hipEventRecord(s->events[3], stream));
-            for (int k = (int)n_levels - 1; k >= 0; k--) {
-                A.cur = s->levels[k].view();
-                A.next = s->levels[k + 1].view();
-                A.count = caps[k];
-                A.count_ptr = k ? s->counters.p + k : nullptr;
-                A.level = (uint32_t)k;
-                launch_combine(A, stream);
-            }
-            RRT_HIP(hipMemcpyAsync(s->host_pinned, s->counters.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             RRT_HIP(hipStreamSynchronize(stream));
-            if (s->host_pinned[63] & RRT_ERR_BIT_QUEUE) {
-                pred.clear();
+            bool overflow = false;
+            for (size_t j = 0; j < plan.size(); j++) overflow |= (s->lanes[j]->host_pinned[63] & RRT_ERR_BIT_QUEUE) != 0;
+            if (overflow) {
+                for (auto &L : s->lanes) L->prediction.clear();
                 retry = true;
                 return RRT_OK;
             }
-            for (uint32_t k = 1; k < n_levels; k++) {
-                counts[k] = s->host_pinned[k];
-                secondary += counts[k];
-            }
-            float ms = 0.0f;
-            RRT_HIP(hipEventElapsedTime(&ms, s->events[2], s->events[3]));
-            ms_trace += ms;
-        } else {
-            for (uint32_t k = 0; k < n_levels; k++) {
-                bool spawns = k + 1 < n_levels;
-                if (spawns && (rc = s->levels[k + 1].ensure(2 * counts[k], n_lights, true))) return rc;
-                A.cur = s->levels[k].view();
-                A.next = s->levels[k + 1].view();
-                A.count = counts[k];
-                A.count_ptr = nullptr;
-                A.next_limit = spawns ? 2 * counts[k] : 0;
-                A.level = k;
-                A.next_count = s->counters.p + (k + 1);
-                RRT_HIP(hipEventRecord(s->events[2], stream));
-                launch_trace_shade(A, D.lds_bytes, stream);
-                RRT_HIP(hipEventRecord(s->events[3], stream));
-                last = k;
-                uint32_t next_n = 0;
-                if (spawns) {
-                    RRT_HIP(hipMemcpyAsync(s->host_pinned, s->counters.p + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                    RRT_HIP(hipStreamSynchronize(stream));
-                    next_n = s->host_pinned[0];
-                } else {
-                    RRT_HIP(hipStreamSynchronize(stream));
+            float first = 0.0f, last = 0.0f;  // wall-clock span of the trace launches of this round
+            for (size_t j = 0; j < plan.size(); j++) {
+                RenderLane &L = *s->lanes[j];
+                err |= L.host_pinned[63];
+                for (uint32_t k = 1; k < n_levels; k++) {
+                    plan[j].counts[k] = L.host_pinned[k];
+                    secondary += L.host_pinned[k];
                 }
-                float ms = 0.0f;
-                RRT_HIP(hipEventElapsedTime(&ms, s->events[2], s->events[3]));
-                ms_trace += ms;
-                counts[k + 1] = next_n;
-                secondary += next_n;
-                if (next_n == 0) break;
+                float t0 = 0.0f, t1 = 0.0f;
+                RRT_HIP(hipEventElapsedTime(&t0, s->events[0], L.ev_trace0));
+                RRT_HIP(hipEventElapsedTime(&t1, s->events[0], L.ev_trace1));
+                first = j == 0 ? t0 : std::min(first, t0);
+                last = j == 0 ? t1 : std::max(last, t1);
             }
-            for (int k = (int)last; k >= 0; k--) {
-                A.cur = s->levels[k].view();
-                A.next = s->levels[k + 1].view();
-                A.count = counts[k];
-                A.count_ptr = nullptr;
-                A.level = (uint32_t)k;
-                launch_combine(A, stream);
+            ms_trace += last - first;
+        } else {  // level by level, one chunk after the other, on the caller's stream
+            for (size_t j = 0; j < plan.size(); j++) {
+                RenderLane &L = *s->lanes[j];
+                std::vector<uint32_t> &counts = plan[j].counts;
+                if ((rc = L.levels[0].ensure(plan[j].n, n_lights, cam == nullptr))) return rc;
+                RRT_HIP(hipMemsetAsync(L.counters.p, 0, 64 * sizeof(uint32_t), stream));
+                if (!cam)
+                    launch_load_rays(origins_dev + (size_t)plan[j].base * 3, directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), stream);
+                TraceArgs A;
+                fill_args(s, A, cam, y0, n_pixels, plan[j].base, depth_cap, L, rgb_dev, depth_dev, id_dev);
+                uint32_t last = 0;
+                for (uint32_t k = 0; k < n_levels; k++) {
+                    bool spawns = k + 1 < n_levels;
+                    if (spawns && (rc = L.levels[k + 1].ensure(2 * counts[k], n_lights, true))) return rc;
+                    A.cur = L.levels[k].view();
+                    A.next = L.levels[k + 1].view();
+                    A.count = counts[k];
+                    A.count_ptr = nullptr;
+                    A.next_limit = spawns ? 2 * counts[k] : 0;
+                    A.level = k;
+                    A.next_count = L.counters.p + (k + 1);
+                    RRT_HIP(hipEventRecord(L.ev_trace0, stream));
+                    launch_trace_shade(A, D.lds_bytes, stream);
+                    RRT_HIP(hipEventRecord(L.ev_trace1, stream));
+                    last = k;
+                    uint32_t next_n = 0;
+                    if (spawns) {
+                        RRT_HIP(hipMemcpyAsync(L.host_pinned, L.counters.p + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                        RRT_HIP(hipStreamSynchronize(stream));
+                        next_n = L.host_pinned[0];
+                    } else {
+                        RRT_HIP(hipStreamSynchronize(stream));
+                    }
+                    float ms = 0.0f;
+                    RRT_HIP(hipEventElapsedTime(&ms, L.ev_trace0, L.ev_trace1));
+                    ms_trace += ms;
+                    counts[k + 1] = next_n;
+                    secondary += next_n;
+                    if (next_n == 0) break;
+                }
+                for (int k = (int)last; k >= 0; k--) {
+                    A.cur = L.levels[k].view();
+                    A.next = L.levels[k + 1].view();
+                    A.count = counts[k];
+                    A.count_ptr = nullptr;
+                    A.level = (uint32_t)k;
+                    launch_combine(A, stream);
+                }
+                RRT_HIP(hipMemcpyAsync(L.host_pinned, L.counters.p + 63, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                RRT_HIP(hipStreamSynchronize(stream));
+                err |= L.host_pinned[0];
             }
         }
-        if (n_levels > 1) {  // what the next frame of this size will be launched for
-            pred.assign(n_levels + 2, 0);
-            pred[0] = n;
-            for (uint32_t k = 0; k <= n_levels; k++) pred[1 + k] = counts[k];
-        }
+        if (n_levels > 1)  // what the next frame's chunks of these sizes will be launched for
+            for (size_t j = 0; j < plan.size(); j++) {
+                std::vector<uint32_t> &pred = s->lanes[j]->prediction;
+                pred.assign(n_levels + 2, 0);
+                pred[0] = plan[j].n;
+                for (uint32_t k = 0; k <= n_levels; k++) pred[1 + k] = plan[j].counts[k];
+            }
     }
     RRT_HIP(hipEventRecord(s->events[1], stream));
-    RRT_HIP(hipMemcpyAsync(s->host_pinned, err_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    unsigned long long st[ST_COUNT];
-    RRT_HIP(hipMemcpyAsync(st, s->stats_dev.p, sizeof(st), hipMemcpyDeviceToHost, stream));
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(s->host_pinned);  // 64 words = room for ST_COUNT slots
+    RRT_HIP(hipMemcpyAsync(st, s->stats_dev.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     RRT_HIP(hipStreamSynchronize(stream));
     float ms_total = 0.0f;
     RRT_HIP(hipEventElapsedTime(&ms_total, s->events[0], s->events[1]));
@@ -658,7 +764,6 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     R.flops_algorithmic = (R.rays_primary + R.rays_secondary + R.rays_shadow) * D.flops_per_trace + 27ull * st[ST_NODES] + 61ull * st[ST_TRIS];
     R.ms_trace_kernels = ms_trace;
     R.ms_total = ms_total;
-    uint32_t err = s->host_pinned[0];
     if (err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");
     if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
     if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
@@ -672,6 +777,7 @@ int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixe
     static const bool level_sync = getenv("RRT_LEVEL_SYNC") != nullptr;  // debugging aid: always size levels by readback
     bool retry = false;
     int rc = render_rays_impl(s, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream, !level_sync, retry);
+    if (rc == RRT_OK && retry) s->stats.frames_repeated++;
     if (rc == RRT_OK && retry)
         rc = render_rays_impl(s, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream, false, retry);
     return rc;

@@ -100,6 +100,19 @@ struct CausticSeeds {
 
 }  // namespace rrt
 
+namespace rrt {
+// One chunk of a frame in flight: its own level queues, counters, readback staging and stream.  Lane 0 runs on the
+// caller's stream; the others on streams of their own, forked from and joined to the caller's stream with events.
+struct RenderLane {
+    std::vector<LevelStorage> levels;
+    DBuf<uint32_t> counters;  // [k] = rays queued for level k, [63] = error bits
+    uint32_t *host_pinned = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_trace0 = nullptr, ev_trace1 = nullptr, ev_done = nullptr;
+    std::vector<uint32_t> prediction;  // [0] = chunk size it was measured on, [1 + k] = size of level k
+};
+}  // namespace rrt
+
 struct rrt_scene {
     int mode = RRT_MODE_SCENE;
     rrt_params params{};
@@ -114,9 +127,8 @@ struct rrt_scene {
     bool maps_built = false;
     uint64_t seed = 0;
     rrt::DeviceScene dev;
-    std::vector<rrt::LevelStorage> levels;
-    std::vector<uint32_t> level_prediction;  // level sizes of the previous frame, see render_rays
-    rrt::DBuf<uint32_t> counters;             // per-level queue lengths + error word
+    std::vector<std::unique_ptr<rrt::RenderLane>> lanes;  // see render_rays (DBuf is not movable: lanes stay put)
+    rrt::DBuf<uint32_t> counters;             // error word of the batch entry points
     rrt::DBuf<unsigned long long> stats_dev;  // StatSlot counters
     uint32_t *host_pinned = nullptr;          // readback staging
     rrt_stats stats{};

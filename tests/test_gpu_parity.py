@@ -110,6 +110,32 @@ def test_predicted_level_sizes_and_their_fallback(repo):
     assert np.array_equal(first[2], id_c) and np.array_equal(bits(first[1]), bits(depth_c))
 
 
+def test_chunks_on_several_streams_match_single_stream_and_oracle(repo):
+    """With rrt_params.render_streams > 1, frames of 2^18 pixels and more are cut into one chunk per stream so that deep
+    recursion levels of one chunk may overlap shallow levels of another: same bits as on one stream, same as the oracle."""
+    cpu, gpu, cam = load_pair(repo, "c2_quadric_csg_fresnel", params=rrt.default_params(render_streams=4))
+    cam.width, cam.height = 648, 420  # 272160 pixels: 4 chunks of 68096 (whole 256-blocks) with a ragged last one
+    gpu.pre_render(1)
+    a1 = gpu.render(cam)  # first frame: level sizes by readback, chunk after chunk
+    a2 = gpu.render(cam)  # second frame: predicted sizes, chunks in flight together
+    s2 = gpu.stats()
+    one, _ = rrt.Scene.load(os.path.join(repo, "assets/scenes/c2_quadric_csg_fresnel.txt"), params=rrt.default_params(render_streams=1),
+                            mode_override=abi.MODE_SCENE)
+    one.pre_render(1)
+    b1 = one.render(cam)
+    b2 = one.render(cam)
+    s1 = one.stats()
+    for x in (a2, b1, b2):
+        for u, v in zip(a1, x):
+            assert np.array_equal(bits(u), bits(v))
+    for k in ("rays_primary", "rays_secondary", "rays_shadow"):
+        assert s1[k] == s2[k], k
+    rgb_c, depth_c, id_c = cpu.render(cam)
+    assert np.array_equal(a1[2], id_c) and np.array_equal(bits(a1[1]), bits(depth_c))
+    assert np.abs(rrt.quantise(a1[0]).astype(int) - ob.quantise(rgb_c).astype(int)).max() <= 1
+    assert cpu.stats()["rays_secondary"] == s2["rays_secondary"] and cpu.stats()["rays_shadow"] == s2["rays_shadow"]
+
+
 @pytest.mark.parametrize("name", REFERENCE_SCENES)
 def test_trace_and_shadowtrace_match_oracle_on_random_rays(repo, name):
     cpu, gpu, cam = load_pair(repo, name)
