@@ -8,11 +8,22 @@ scene resident in HBM, outputs written to HBM.  Metric: Mrays/s = (primary + sec
 rays traced) / wall time.  With N ranks every rank renders its own frame of a camera orbit per step
 (frames are independent objects: no data-path collective), so scaling is "weak".
 
-Extra legs (same JSON line): `cpu_baseline` = the CPU oracle (a port of the reference's brute-force
-algorithm; the Rust binary cannot be built here) on a bounded sample of rows of the same frame;
-`roofline` = k_trace_shade against the MI355X vector-FP32 peak, timed with HIP events on the launch
-stream inside librrt (rrt_stats.ms_trace_kernels); `mesh` and `photon` = the other two single-GPU
-configs of BASELINE.json, short runs.
+Extra legs (same JSON line):
+  `cpu_baseline`  the CPU oracle (a port of the reference's brute-force algorithm; the Rust binary cannot be
+                  built here: no Rust toolchain) rendering whole frames of the same workload for >= 12 s on
+                  min(16, cpus) threads, row bands like camera.rs:14-42.
+  `roofline`      k_trace_shade, the kernel that holds ~88 % of the GPU time.  It is neither HBM- nor MFMA-bound:
+                  ray/primitive intersection is divergent scalar-per-lane FP32 work with IEEE division and
+                  square roots that may not be contracted into FMAs (bit-exact parity), so the ceiling that
+                  applies is the vector FP32 rate ("valu_fp32", 157.3 TFLOP/s, which counts an FMA as two).
+                  achieved = algorithmic flops (per-primitive flops of the reference's brute
+                  force loop x rays traced, + 27 per ray/box and 61 per ray/triangle test) / HIP-event time of
+                  the launches on their stream (rrt_stats.ms_trace_kernels).  `traffic` = HBM bytes per launch
+                  from the committed PMC passes (profiles/r01_final/pmc_traffic.json, FETCH_SIZE doubled as
+                  the MI355X guide prescribes for 16-B-per-lane reads); `hbm_frac` prices the same launches
+                  against 8 TB/s to show how far from the HBM roof the kernel is.
+  `extra`         the other two single-GPU configs of BASELINE.json (1M-triangle mesh at 4K, 1M photons),
+                  short runs (bench_extra.py).
 """
 import argparse
 import importlib
@@ -67,6 +78,15 @@ def cpu_baseline(scene_path, cam, min_seconds=12.0):
         "kind": "port",
         "sample": "%d whole 1920x1080 frames of the same scene on %d threads (%d rays, %.1f s)" % (frames, cores, rays, dt),
     }
+
+
+def measured_traffic(scene_path, width, height):
+    """HBM bytes per k_trace_shade launch from the committed PMC passes; only valid for the workload they were taken on."""
+    f = os.path.join(REPO, "profiles/r01_final/pmc_traffic.json")
+    if not (os.path.exists(f) and scene_path.endswith("c2_quadric_csg_fresnel.txt") and (width, height) == (1920, 1080)):
+        return None
+    with open(f) as fh:
+        return json.load(fh).get("hbm_bytes_per_launch")
 
 
 def main():
@@ -141,6 +161,9 @@ def main():
 
     if rank == 0:
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        traffic = measured_traffic(args.scene, W, H)
+        launches = 6  # recursion levels 0..5 of a frame
+        hbm_gbs = traffic * launches / (kernel_ms / max(1, args.steps) * 1e-3) / 1e9 if traffic and kernel_ms > 0 else None
         out = {
             "metric": "Mrays/s (primary+secondary+shadow rays traced)",
             "value": total_rays / dt / 1e6,
@@ -168,7 +191,11 @@ def main():
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_final/pmc_traffic.json)",
+                "hbm_gb_per_s": hbm_gbs,
+                "hbm_frac": hbm_gbs / PEAK_HBM_GBS if hbm_gbs else None,
+                "launches_per_frame": launches,
                 "kernel_ms_per_frame": kernel_ms / max(1, args.steps),
                 "algorithmic_flops_per_frame": flops // max(1, args.steps),
             },
