@@ -87,6 +87,40 @@ struct GatherSums {
     uint32_t candidates;
 };
 
+// cell key -> (first record, count) through the open-addressing table
+__device__ __forceinline__ uint2 lookup_cell(const DevPhotonMap &G, uint64_t key) {
+    uint32_t slot = hash_key(key) & G.table_mask;
+    for (;;) {
+        uint64_t k = G.keys[slot];
+        if (k == key) return G.ranges[slot];
+        if (k == ~0ULL) return make_uint2(0, 0);
+        slot = (slot + 1) & G.table_mask;
+    }
+}
+
+// closed-box test of one candidate record; incident / intensity are read for the records inside only
+__device__ __forceinline__ void take_record(const DevPhotonMap &G, uint32_t i, float4 q, f3 lo, f3 hi, GatherSums &s) {
+    if (q.x >= lo.x && q.x <= hi.x && q.y >= lo.y && q.y <= hi.y && q.z >= lo.z && q.z <= hi.z) {
+        float4 d = G.incident[i];
+        float4 c = G.intensity[i];
+        s.ldir = s.ldir + mk3(d.x, d.y, d.z);
+        s.intensity = s.intensity + mk3(c.x, c.y, c.z);
+        s.k++;
+    }
+}
+__device__ __forceinline__ void stream_cell(const DevPhotonMap &G, uint2 range, f3 lo, f3 hi, GatherSums &s) {
+    s.candidates += range.y;
+    uint32_t i = range.x, end = range.x + range.y;
+    for (; i + 4 <= end; i += 4) {  // four independent position loads in flight
+        float4 q0 = G.pos_cell[i], q1 = G.pos_cell[i + 1], q2 = G.pos_cell[i + 2], q3 = G.pos_cell[i + 3];
+        take_record(G, i, q0, lo, hi, s);
+        take_record(G, i + 1, q1, lo, hi, s);
+        take_record(G, i + 2, q2, lo, hi, s);
+        take_record(G, i + 3, q3, lo, hi, s);
+    }
+    for (; i < end; i++) take_record(G, i, G.pos_cell[i], lo, hi, s);
+}
+
 // PhotonTree::get_within_distance (photon_tree.rs:15-35) + the accumulation of
 // average_photon_of_type_at (photon_scene.rs:401-407).  The reference adds in order of distance,
 // this adds in cell order: same set, f32 sums differ by rounding only.
@@ -100,33 +134,24 @@ __device__ __forceinline__ void gather_box(const DevPhotonMap &G, f3 p, float r,
     uint32_t x0 = cell_coord(lo.x, G.inv_cell), x1 = cell_coord(hi.x, G.inv_cell);
     uint32_t y0 = cell_coord(lo.y, G.inv_cell), y1 = cell_coord(hi.y, G.inv_cell);
     uint32_t z0 = cell_coord(lo.z, G.inv_cell), z1 = cell_coord(hi.z, G.inv_cell);
-    for (uint32_t cx = x0; cx <= x1; cx++)
-        for (uint32_t cy = y0; cy <= y1; cy++)
-            for (uint32_t cz = z0; cz <= z1; cz++) {
-                uint64_t key = cell_key(cx, cy, cz);
-                uint32_t slot = hash_key(key) & G.table_mask;
-                uint2 range = make_uint2(0, 0);
-                for (;;) {
-                    uint64_t k = G.keys[slot];
-                    if (k == key) {
-                        range = G.ranges[slot];
-                        break;
-                    }
-                    if (k == ~0ULL) break;
-                    slot = (slot + 1) & G.table_mask;
-                }
-                s.candidates += range.y;
-                for (uint32_t i = range.x; i < range.x + range.y; i++) {
-                    float4 q = G.pos_cell[i];
-                    if (q.x >= lo.x && q.x <= hi.x && q.y >= lo.y && q.y <= hi.y && q.z >= lo.z && q.z <= hi.z) {
-                        float4 d = G.incident[i];
-                        float4 c = G.intensity[i];
-                        s.ldir = s.ldir + mk3(d.x, d.y, d.z);
-                        s.intensity = s.intensity + mk3(c.x, c.y, c.z);
-                        s.k++;
-                    }
-                }
-            }
+    // Two phases, so that the memory system sees independent requests instead of one dependent chain per lane:
+    // first every overlapped cell's (first, count) is looked up, then the cells are streamed four records at a time.
+    // The order of accumulation (cells x-major, records ascending) is the same either way.
+    const bool small = x1 - x0 <= 1u && y1 - y0 <= 1u && z1 - z0 <= 1u;  // cell edge = 2r: always, barring rounding
+    if (small) {
+        uint2 rg[8];
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) {
+            uint32_t cx = x0 + (c >> 2), cy = y0 + ((c >> 1) & 1u), cz = z0 + (c & 1u);
+            rg[c] = (cx <= x1 && cy <= y1 && cz <= z1) ? lookup_cell(G, cell_key(cx, cy, cz)) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) stream_cell(G, rg[c], lo, hi, s);
+    } else {
+        for (uint32_t cx = x0; cx <= x1; cx++)
+            for (uint32_t cy = y0; cy <= y1; cy++)
+                for (uint32_t cz = z0; cz <= z1; cz++) stream_cell(G, lookup_cell(G, cell_key(cx, cy, cz)), lo, hi, s);
+    }
 }
 
 // average_photon_at (photon_scene.rs:363-420): regular and caustic estimates and their blend
