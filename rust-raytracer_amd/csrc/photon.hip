@@ -331,14 +331,13 @@ __global__ void k_strip_key(const uint64_t *meta, uint32_t n, uint64_t *key) {
 static inline dim3 grid_for(uint64_t n, uint32_t block = 256) { return dim3((uint32_t)((n + block - 1) / block)); }
 
 // stable radix sort of (key, index) pairs with rocPRIM
-static int sort_pairs(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in, uint32_t *idx_out, uint32_t n, hipStream_t st) {
+static int sort_pairs(PhotonScratch &W, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in, uint32_t *idx_out, uint32_t n,
+                      hipStream_t st) {
     size_t temp_bytes = 0;
     RRT_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, 0, 64, st));
-    DBuf<uint8_t> temp;
-    int rc = temp.ensure(temp_bytes ? temp_bytes : 1);
+    int rc = W.sort_temp.ensure(temp_bytes ? temp_bytes : 1);
     if (rc) return rc;
-    RRT_HIP(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, 0, 64, st));
-    RRT_HIP(hipStreamSynchronize(st));
+    RRT_HIP(rocprim::radix_sort_pairs(W.sort_temp.p, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, 0, 64, st));
     return RRT_OK;
 }
 
@@ -362,21 +361,23 @@ static int grow_photons(PhotonBuffers &b, uint64_t need) {
 }
 
 // canonical order: sort the records of a buffer by meta (light, pass, key)
-static int sort_by_meta(PhotonBuffers &b) {
+static int sort_by_meta(PhotonScratch &W, PhotonBuffers &b) {
     uint32_t n = (uint32_t)b.count;
     if (n < 2) return RRT_OK;
-    DBuf<uint32_t> idx, idx2;
-    DBuf<uint64_t> k2;
-    DBuf<float4> t;
     int rc;
-    if ((rc = idx.ensure(n)) || (rc = idx2.ensure(n)) || (rc = k2.ensure(n)) || (rc = t.ensure(n))) return rc;
-    hipLaunchKernelGGL(k_iota, grid_for(n), dim3(256), 0, nullptr, idx.p, n);
-    if ((rc = sort_pairs(b.meta.p, k2.p, idx.p, idx2.p, n, nullptr))) return rc;
-    RRT_HIP(hipMemcpy(b.meta.p, k2.p, (size_t)n * 8, hipMemcpyDeviceToDevice));
+    // the sorted arrays replace the unsorted ones by pointer swap, so the work arrays are as large as the buffers
+    size_t cap = std::max<size_t>(n, b.pos.cap);
+    if ((rc = W.idx.ensure(n)) || (rc = W.idx2.ensure(n)) || (rc = W.keys2.ensure(std::max<size_t>(n, b.meta.cap))) || (rc = W.t.ensure(cap))) return rc;
+    hipLaunchKernelGGL(k_iota, grid_for(n), dim3(256), 0, nullptr, W.idx.p, n);
+    if ((rc = sort_pairs(W, b.meta.p, W.keys2.p, W.idx.p, W.idx2.p, n, nullptr))) return rc;
+    std::swap(b.meta.p, W.keys2.p);
+    std::swap(b.meta.cap, W.keys2.cap);
     DBuf<float4> *arrs[3] = {&b.pos, &b.dir, &b.rgb};
     for (auto *a : arrs) {
-        hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, a->p, idx2.p, n, t.p);
-        RRT_HIP(hipMemcpy(a->p, t.p, (size_t)n * 16, hipMemcpyDeviceToDevice));
+        if ((rc = W.t.ensure(std::max<size_t>(n, a->cap)))) return rc;
+        hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, a->p, W.idx2.p, n, W.t.p);
+        std::swap(a->p, W.t.p);
+        std::swap(a->cap, W.t.cap);
     }
     return RRT_OK;
 }
@@ -390,17 +391,18 @@ static int build_index(rrt_scene *s, int which) {
     X.table_size = 0;
     if (n == 0) return RRT_OK;
     int rc;
-    if ((rc = sort_by_meta(b))) return rc;  // canonical order first; the cell sort below is stable
-    DBuf<uint64_t> keys, keys2;
-    DBuf<uint32_t> idx, idx2, ncell;
+    PhotonScratch &W = s->photon_scratch;
+    if ((rc = sort_by_meta(W, b))) return rc;  // canonical order first; the cell sort below is stable
+    DBuf<uint64_t> &keys = W.keys, &keys2 = W.keys2;
+    DBuf<uint32_t> &idx = W.idx, &idx2 = W.idx2, &ncell = W.ncell;
     if ((rc = keys.ensure(n)) || (rc = keys2.ensure(n)) || (rc = idx.ensure(n)) || (rc = idx2.ensure(n)) || (rc = ncell.ensure(1))) return rc;
     hipLaunchKernelGGL(k_cell_keys, grid_for(n), dim3(256), 0, nullptr, b.pos.p, n, X.inv_cell, keys.p, idx.p);
-    if ((rc = sort_pairs(keys.p, keys2.p, idx.p, idx2.p, n, nullptr))) return rc;
+    if ((rc = sort_pairs(W, keys.p, keys2.p, idx.p, idx2.p, n, nullptr))) return rc;
     if ((rc = X.pos.ensure(n)) || (rc = X.dir.ensure(n)) || (rc = X.rgb.ensure(n))) return rc;
     hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.pos.p, idx2.p, n, X.pos.p);
     hipLaunchKernelGGL(k_gather_norm, grid_for(n), dim3(256), 0, nullptr, b.dir.p, idx2.p, n, X.dir.p);
     hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.rgb.p, idx2.p, n, X.rgb.p);
-    RRT_HIP(hipMemset(ncell.p, 0, 4));
+    RRT_HIP(hipMemsetAsync(ncell.p, 0, 4, nullptr));
     hipLaunchKernelGGL(k_count_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, ncell.p);
     uint32_t cells = 0;
     RRT_HIP(hipMemcpy(&cells, ncell.p, 4, hipMemcpyDeviceToHost));
@@ -421,12 +423,13 @@ static int rebuild_seeds(rrt_scene *s, int light, const float4 *pos, const float
     cs.count = n;
     if (n == 0) return RRT_OK;
     int rc;
-    DBuf<uint32_t> idx, idx2;
-    DBuf<uint64_t> k2;
+    PhotonScratch &W = s->photon_scratch;
+    DBuf<uint32_t> &idx = W.idx, &idx2 = W.idx2;
+    DBuf<uint64_t> &k2 = W.keys2;
     if ((rc = idx.ensure(n)) || (rc = idx2.ensure(n)) || (rc = k2.ensure(n))) return rc;
     if ((rc = cs.pos.ensure(n)) || (rc = cs.dir.ensure(n)) || (rc = cs.key.ensure(n))) return rc;
     hipLaunchKernelGGL(k_iota, grid_for(n), dim3(256), 0, nullptr, idx.p, n);
-    if ((rc = sort_pairs(key, k2.p, idx.p, idx2.p, n, nullptr))) return rc;
+    if ((rc = sort_pairs(W, key, k2.p, idx.p, idx2.p, n, nullptr))) return rc;
     hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, pos, idx2.p, n, cs.pos.p);
     hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, dir, idx2.p, n, cs.dir.p);
     RRT_HIP(hipMemcpy(cs.key.p, k2.p, (size_t)n * 8, hipMemcpyDeviceToDevice));
@@ -590,7 +593,7 @@ int rrt_photon_read(rrt_scene *s, int which, float *position, float *incident, f
     PhotonBuffers &b = s->local[which];
     size_t n = b.count;
     if (n == 0) return RRT_OK;
-    int rc = sort_by_meta(b);
+    int rc = sort_by_meta(s->photon_scratch, b);
     if (rc) return rc;
     std::vector<float4> tmp(n);
     auto pull = [&](const float4 *src, float *dst, uint8_t *ty) -> int {

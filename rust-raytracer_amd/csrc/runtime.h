@@ -92,6 +92,14 @@ struct PhotonIndex {
     float inv_cell = 0.0f;
     DevPhotonMap view() const;
 };
+// Work arrays of the sorts and the index build, kept between calls (grow-only): hipMalloc / hipFree cost more than the
+// sorts themselves at a few million records.
+struct PhotonScratch {
+    DBuf<uint32_t> idx, idx2, ncell;
+    DBuf<uint64_t> keys, keys2;
+    DBuf<float4> t;
+    DBuf<uint8_t> sort_temp;
+};
 struct CausticSeeds {
     DBuf<float4> pos, dir;
     DBuf<uint64_t> key;
@@ -138,6 +146,7 @@ struct rrt_scene {
     rrt::PhotonBuffers local[2];  // this rank's records: regular, caustic
     std::vector<std::unique_ptr<rrt::CausticSeeds>> seeds;  // per light
     rrt::PhotonIndex index[2];
+    rrt::PhotonScratch photon_scratch;
 
     ~rrt_scene();
 };
