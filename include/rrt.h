@@ -321,6 +321,13 @@ int rrt_photon_export_device(rrt_scene *s, int which, float *pos_dev, float *inc
                              float *intensity_dev, uint64_t *meta_dev);
 int rrt_photon_import_device(rrt_scene *s, int which, const float *pos_dev, const float *incident_dev,
                              const float *intensity_dev, const uint64_t *meta_dev, uint64_t count);
+
+/* Photon-map files: both maps of this rank (after rrt_photon_build's canonical sort order), so that cameras can be
+ * re-rendered without re-shooting.  No counterpart in the reference (its maps live and die with the process);
+ * SURVEY.md 8f rank 2.  Load needs rrt_photon_begin on the same scene first and rrt_photon_build after it.
+ * Format: DESIGN.md "photon-map files".                                                          */
+int rrt_photon_save(rrt_scene *s, const char *path);
+int rrt_photon_load(rrt_scene *s, const char *path);
 int rrt_photon_build(rrt_scene *s);
 
 int rrt_get_stats(const rrt_scene *s, rrt_stats *out);

@@ -101,6 +101,8 @@ _sig("rrt_photon_caustic_export_device", C.c_int, C.c_void_p, C.c_int, C.c_void_
 _sig("rrt_photon_caustic_import_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 _sig("rrt_photon_local_count", C.c_int, C.c_void_p, C.c_int, _u64p)
 _sig("rrt_photon_export_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("rrt_photon_save", C.c_int, C.c_void_p, C.c_char_p)
+_sig("rrt_photon_load", C.c_int, C.c_void_p, C.c_char_p)
 _sig("rrt_photon_import_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 _sig("rrt_get_stats", C.c_int, C.c_void_p, C.POINTER(Stats))
 _sig("rrt_quantise", None, _f32p, C.c_size_t, _u8p)
@@ -342,6 +344,12 @@ class Scene:
 
     def photon_import_device(self, which, pos4_ptr, incident4_ptr, intensity4_ptr, meta_ptr, count):
         check(lib.rrt_photon_import_device(self._h, which, pos4_ptr, incident4_ptr, intensity4_ptr, meta_ptr, count))
+
+    def photon_save(self, path):
+        check(lib.rrt_photon_save(self._h, str(path).encode()))
+
+    def photon_load(self, path):
+        check(lib.rrt_photon_load(self._h, str(path).encode()))
 
     def stats(self):
         st = Stats()

@@ -670,4 +670,98 @@ int rrt_photon_import_device(rrt_scene *s, int which, const float *pos4_dev, con
     return RRT_OK;
 }
 
+// ---- photon-map files (keep the maps between runs, re-render without re-shooting) ----
+// Layout, little endian: "RRTPMAP1", u32 version (1), u32 bytes per record (56), u64 seed, u64 count[2], then per map
+// pos[count] float4 (w = type), incident[count] float4, intensity[count] float4, meta[count] u64, in canonical order.
+namespace {
+struct PmapHeader {
+    char magic[8];
+    uint32_t version, record_bytes;
+    uint64_t seed, count[2];
+};
+const size_t kPmapChunk = 1u << 22;  // records per host staging chunk (64 MiB of float4)
+}  // namespace
+
+int rrt_photon_save(rrt_scene *s, const char *path) {
+    if (!s || !path) return fail(RRT_ERR_INVALID, "null argument");
+    if (s->mode != RRT_MODE_PHOTON) return fail(RRT_ERR_STATE, "scene is not a PhotonScene");
+    int rc;
+    for (int w = 0; w < 2; w++)
+        if ((rc = sort_by_meta(s->photon_scratch, s->local[w]))) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(RRT_ERR_IO, std::string("cannot write ") + path);
+    PmapHeader h;
+    memcpy(h.magic, "RRTPMAP1", 8);
+    h.version = 1;
+    h.record_bytes = 56;
+    h.seed = s->seed;
+    h.count[0] = s->local[0].count;
+    h.count[1] = s->local[1].count;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    std::vector<uint8_t> stage(kPmapChunk * 16);
+    for (int w = 0; w < 2 && ok; w++) {
+        PhotonBuffers &b = s->local[w];
+        const void *arrs[4] = {b.pos.p, b.dir.p, b.rgb.p, b.meta.p};
+        const size_t elem[4] = {16, 16, 16, 8};
+        for (int a = 0; a < 4 && ok; a++)
+            for (size_t i = 0; i < b.count && ok; i += kPmapChunk) {
+                size_t n = std::min<size_t>(kPmapChunk, b.count - i);
+                if (hipMemcpy(stage.data(), (const uint8_t *)arrs[a] + i * elem[a], n * elem[a], hipMemcpyDeviceToHost) != hipSuccess) {
+                    fclose(f);
+                    return fail(RRT_ERR_DEVICE, "hipMemcpy failed while saving the photon maps");
+                }
+                ok = fwrite(stage.data(), elem[a], n, f) == n;
+            }
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(RRT_ERR_IO, std::string("short write to ") + path);
+    return RRT_OK;
+}
+
+int rrt_photon_load(rrt_scene *s, const char *path) {
+    if (!s || !path) return fail(RRT_ERR_INVALID, "null argument");
+    if (s->mode != RRT_MODE_PHOTON) return fail(RRT_ERR_STATE, "scene is not a PhotonScene");
+    if (!s->flattened || s->seeds.size() != s->lights.size()) return fail(RRT_ERR_STATE, "rrt_photon_begin has not been called");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(RRT_ERR_IO, std::string("cannot open ") + path);
+    PmapHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RRTPMAP1", 8) != 0 || h.version != 1 || h.record_bytes != 56) {
+        fclose(f);
+        return fail(RRT_ERR_PARSE, std::string(path) + " is not a photon-map file of this build (RRTPMAP1, version 1)");
+    }
+    if (h.count[0] >= (1ull << 32) || h.count[1] >= (1ull << 32)) {
+        fclose(f);
+        return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
+    }
+    std::vector<uint8_t> stage(kPmapChunk * 16);
+    for (int w = 0; w < 2; w++) {
+        PhotonBuffers &b = s->local[w];
+        b.count = 0;
+        int rc = grow_photons(b, h.count[w] ? h.count[w] : 1);
+        if (rc) {
+            fclose(f);
+            return rc;
+        }
+        void *arrs[4] = {b.pos.p, b.dir.p, b.rgb.p, b.meta.p};
+        const size_t elem[4] = {16, 16, 16, 8};
+        for (int a = 0; a < 4; a++)
+            for (size_t i = 0; i < h.count[w]; i += kPmapChunk) {
+                size_t n = std::min<size_t>(kPmapChunk, h.count[w] - i);
+                if (fread(stage.data(), elem[a], n, f) != n) {
+                    fclose(f);
+                    return fail(RRT_ERR_IO, std::string("short read from ") + path);
+                }
+                if (hipMemcpy((uint8_t *)arrs[a] + i * elem[a], stage.data(), n * elem[a], hipMemcpyHostToDevice) != hipSuccess) {
+                    fclose(f);
+                    return fail(RRT_ERR_DEVICE, "hipMemcpy failed while loading the photon maps");
+                }
+            }
+        b.count = h.count[w];
+    }
+    fclose(f);
+    s->seed = h.seed;
+    s->maps_built = false;
+    return RRT_OK;
+}
+
 }  // extern "C"

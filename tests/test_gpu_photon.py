@@ -113,6 +113,38 @@ def test_device_exchange_round_trip(repo):
         assert np.array_equal(a.photon_read(which)["key"], b.photon_read(which)["key"])
 
 
+def test_photon_map_file_round_trip(repo, tmp_path):
+    """rrt_photon_save / rrt_photon_load: a second scene that loads the file instead of shooting renders the same bits."""
+    _, a, cam = pair(repo, "pm_caustics", 20000, 1500)
+    _, b, _ = pair(repo, "pm_caustics", 20000, 1500)
+    a.pre_render(9)
+    f = tmp_path / "maps.rrtpmap"
+    a.photon_save(f)
+    n = [len(a.photon_read(w)["key"]) for w in (0, 1)]
+    assert os.path.getsize(f) == 40 + 56 * sum(n) and min(n) > 0
+    b.photon_begin(1)            # another seed: nothing of it may survive the load
+    b.photon_shoot(0, 0, 0, 500)
+    b.photon_load(f)
+    b.photon_build()
+    for which in (0, 1):
+        pa, pb = a.photon_read(which), b.photon_read(which)
+        for k in pa:
+            assert np.array_equal(pa[k].view(np.uint8), pb[k].view(np.uint8)), (which, k)
+    cam.width = cam.height = 80
+    assert np.array_equal(bits(a.render(cam)[0]), bits(b.render(cam)[0]))
+    # error behaviour: wrong file, missing file, wrong call order
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"not a photon map" * 4)
+    for path, code in ((bad, abi.ERR_PARSE), (tmp_path / "missing", abi.ERR_IO)):
+        with pytest.raises(rrt.RrtError) as e:
+            b.photon_load(path)
+        assert e.value.code == code
+    c = pair(repo, "pm_caustics", 20000, 1500)[1]
+    with pytest.raises(rrt.RrtError) as e:
+        c.photon_load(f)         # rrt_photon_begin first
+    assert e.value.code == abi.ERR_STATE
+
+
 def test_index_finds_exactly_the_photons_in_the_closed_cube(repo):
     cpu, gpu, cam = pair(repo, "pm_caustics", 60000, 2000)
     cpu.pre_render(11)
