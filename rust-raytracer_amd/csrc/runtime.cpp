@@ -594,6 +594,8 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     uint64_t secondary = 0;
     float ms_trace = 0.0f;
     uint32_t err = 0;
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(s->host_pinned);  // 64 words = room for ST_COUNT slots
+    bool tail_done = false;
 
     for (uint32_t round_base = 0; round_base < n_pixels;) {
         // the chunks of this round, one per lane
@@ -660,6 +662,11 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     RRT_HIP(hipEventRecord(L.ev_done, st));
                     RRT_HIP(hipStreamWaitEvent(stream, L.ev_done, 0));
                 }
+            }
+            if (round_base >= n_pixels) {  // last round: the frame's end event and the stats ride on the same sync
+                RRT_HIP(hipEventRecord(s->events[1], stream));
+                RRT_HIP(hipMemcpyAsync(st, s->stats_dev.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                tail_done = true;
             }
             RRT_HIP(hipStreamSynchronize(stream));
             bool overflow = false;
@@ -745,10 +752,11 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                 for (uint32_t k = 0; k <= n_levels; k++) pred[1 + k] = plan[j].counts[k];
             }
     }
-    RRT_HIP(hipEventRecord(s->events[1], stream));
-    unsigned long long *st = reinterpret_cast<unsigned long long *>(s->host_pinned);  // 64 words = room for ST_COUNT slots
-    RRT_HIP(hipMemcpyAsync(st, s->stats_dev.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    RRT_HIP(hipStreamSynchronize(stream));
+    if (!tail_done) {
+        RRT_HIP(hipEventRecord(s->events[1], stream));
+        RRT_HIP(hipMemcpyAsync(st, s->stats_dev.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        RRT_HIP(hipStreamSynchronize(stream));
+    }
     float ms_total = 0.0f;
     RRT_HIP(hipEventElapsedTime(&ms_total, s->events[0], s->events[1]));
     rrt_stats &R = s->stats;
