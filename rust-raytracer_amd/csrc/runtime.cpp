@@ -827,20 +827,6 @@ void invalidate(rrt_scene *s) {
 
 extern "C" {
 
-const char *rrt_last_error(void) { return rrt::last_error_cstr(); }
-const char *rrt_version(void) { return "rrt 0.1 (gfx950)"; }
-
-void rrt_params_default(rrt_params *p) {
-    memset(p, 0, sizeof(*p));
-    p->photons_per_light = 5000000;
-    p->caustic_photons_per_light = 10000;
-    p->gather_half_width = 0.1f;
-    p->max_depth = 5;
-    p->max_photon_bounces = 64;
-    p->max_vueon_depth = 12;
-    p->chunk_pixels = 0;
-}
-
 rrt_scene *rrt_scene_create(int mode, const rrt_params *params) {
     if (mode != RRT_MODE_SCENE && mode != RRT_MODE_PHOTON) {
         set_error("bad mode");
@@ -1014,44 +1000,6 @@ int rrt_add_light(rrt_scene *s, const rrt_light_desc *d) {
     s->lights.push_back(*d);
     invalidate(s);
     return (int)s->lights.size() - 1;
-}
-
-// full_camera.rs:23-58
-int rrt_camera_init(rrt_camera *cam, uint32_t width, uint32_t height, float fov, const float position[3], const float lookat_in[3],
-                    const float up_in[3]) {
-    if (!cam || !position || !lookat_in || !up_in) return fail(RRT_ERR_INVALID, "null argument");
-    if (width == 0 || height == 0) return fail(RRT_ERR_INVALID, "Invalid framebuffer size");
-    f3 lookat = mk3(lookat_in[0], -lookat_in[1], lookat_in[2]);
-    f3 up = mk3(up_in[0], -up_in[1], up_in[2]);
-    lookat = norm3(lookat);
-    up = norm3(up);
-    float dotp = dot3(lookat, up);
-    float len = len3(lookat) * len3(up);
-    float ang = acosf(dotp) / len;  // vector.rs:114-119
-    const float right_angle = 1.57079632679489661923f;
-    if (fabsf(ang - right_angle) > 0.0001f) return fail(RRT_ERR_INVALID, "FullCamera right and up are not perpendicular");
-    f3 right = norm3(cross3(lookat, up));
-    cam->width = width;
-    cam->height = height;
-    cam->fov = fov;
-    for (int i = 0; i < 3; i++) cam->position[i] = position[i];
-    cam->lookat[0] = lookat.x; cam->lookat[1] = lookat.y; cam->lookat[2] = lookat.z;
-    cam->up[0] = up.x; cam->up[1] = up.y; cam->up[2] = up.z;
-    cam->right[0] = right.x; cam->right[1] = right.y; cam->right[2] = right.z;
-    return RRT_OK;
-}
-
-// full_camera.rs:61-81
-int rrt_camera_ray(const rrt_camera *cam, uint32_t x, uint32_t y, float origin[3], float direction[3]) {
-    if (!cam || x >= cam->width || y >= cam->height) return fail(RRT_ERR_INVALID, "pixel out of range");
-    float fx = ((float)x + 0.5f) / (float)cam->width;
-    float fy = ((float)y + 0.5f) / (float)cam->height;
-    f3 v = mk3(fx - 0.5f, fy - 0.5f, cam->fov);
-    f3 d = norm3(mk3(cam->right[0] * v.x + cam->up[0] * v.y + cam->lookat[0] * v.z, cam->right[1] * v.x + cam->up[1] * v.y + cam->lookat[1] * v.z,
-                     cam->right[2] * v.x + cam->up[2] * v.y + cam->lookat[2] * v.z));
-    for (int i = 0; i < 3; i++) origin[i] = cam->position[i];
-    direction[0] = d.x; direction[1] = d.y; direction[2] = d.z;
-    return RRT_OK;
 }
 
 rrt_scene *rrt_scene_load(const char *path, const char *asset_root, const rrt_params *params, int mode_override, rrt_camera *camera_out) {
