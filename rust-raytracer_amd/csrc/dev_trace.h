@@ -480,9 +480,16 @@ struct CsgState {
 // ---- Environment::trace (environment.rs:34-74) -----------------------------------------------------
 // First entering hit with distance >= 0 over all objects; strict `<` everywhere, so the first hit in
 // list order wins inside an object and the first object wins across objects.
+
+// Scene features a kernel instance is compiled for.  The render kernel is instantiated per feature set (the flags are
+// wave-uniform facts of the scene), so a scene without meshes does not carry the BVH traversal's registers and code, and
+// a scene without CSG does not carry the hit-list machinery.
+enum SceneFeatures : int { FEAT_CSG = 1, FEAT_MESH = 2, FEAT_ALL = 3 };
+
 // The one entering hit a single-primitive object can produce (list position 0 of a plane, t0 of a
 // sphere / quadric, the cuboid's first_hit, the mesh's closest hit when it faces the ray), with the
 // reference's `distance < 0 -> skip` applied.  `mesh_bound`: only mesh hits below it are searched.
+template <int FEAT = FEAT_ALL>
 __device__ __forceinline__ bool single_entering_hit(const DevScene &S, const ProgRec &r, f3 o, f3 d, float mesh_bound, Lds &lds,
                                                     Counters &cnt, float &t_out, uint32_t &sub_out) {
     sub_out = 0;
@@ -520,6 +527,7 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, const Pro
             return true;
         }
         case OP_MESH: {
+            if (!(FEAT & FEAT_MESH)) return false;  // this instance serves scenes without meshes
             float t;
             uint32_t slot;
             bool ent;
@@ -586,11 +594,12 @@ __device__ __forceinline__ bool bound_hit(const ProgRec &r, const RayBox &rb, f3
 
 // One step of the object loop shared by trace and shadowtrace: feeds record k, and reports the object's first
 // entering hit once the object's last record has been consumed.
+template <int FEAT = FEAT_ALL>
 __device__ __forceinline__ bool object_step(const DevScene &S, uint32_t k, const ProgRec &r, CsgState &csg, f3 o, f3 d, float bound, Lds &lds,
                                             Counters &cnt, float &t_out, uint32_t &k_out, uint32_t &sub_out) {
-    if (!(r.op & PF_CSG)) {
+    if (!(FEAT & FEAT_CSG) || !(r.op & PF_CSG)) {
         k_out = k;
-        if (!single_entering_hit(S, r, o, d, bound, lds, cnt, t_out, sub_out)) return false;
+        if (!single_entering_hit<FEAT>(S, r, o, d, bound, lds, cnt, t_out, sub_out)) return false;
         return t_out < RRT_F32_MAX;  // select_first_hit starts from f32::MAX with a strict `<`
     }
     if (r.op & PF_FIRST) csg.reset();
@@ -599,6 +608,7 @@ __device__ __forceinline__ bool object_step(const DevScene &S, uint32_t k, const
     return csg_first_hit(lds, csg.out_slot(), csg.out_len(), t_out, k_out, sub_out);
 }
 
+template <int FEAT = FEAT_ALL>
 __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, Counters &cnt, TraceResult &r) {
     r.object = 0xFFFFFFFFu;
     r.t = RRT_F32_MAX;
@@ -610,16 +620,16 @@ __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, C
     for (uint32_t k = 0; k < S.n_prog; k++) {
         const ProgRec &rec = S.prog[k];
         if ((rec.op & 0xFFu) == OP_BOUND) {
-            if (rec.op & PF_FIRST) csg.reset();
+            if ((FEAT & FEAT_CSG) && (rec.op & PF_FIRST)) csg.reset();
             if (!__any(bound_hit(rec, rb, o))) {
                 k += rec.aux;
-                if (rec.op & PF_CSG) csg.push_empty();  // bound of a sub-tree inside a CSG program
+                if ((FEAT & FEAT_CSG) && (rec.op & PF_CSG)) csg.push_empty();  // bound of a sub-tree inside a CSG program
             }
             continue;
         }
         float t;
         uint32_t kk, sub;
-        if (!object_step(S, k, rec, csg, o, d, r.t, lds, cnt, t, kk, sub)) continue;
+        if (!object_step<FEAT>(S, k, rec, csg, o, d, r.t, lds, cnt, t, kk, sub)) continue;
         if (t < r.t) {
             r.t = t;
             r.object = rec.object;
@@ -630,6 +640,7 @@ __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, C
 }
 
 // Scene::shadowtrace (scene.rs:65-79)
+template <int FEAT = FEAT_ALL>
 __device__ __forceinline__ bool shadowtrace(const DevScene &S, f3 o, f3 d, float limit, Lds &lds, Counters &cnt) {
     cnt.shadow++;
     CsgState csg;
@@ -638,10 +649,10 @@ __device__ __forceinline__ bool shadowtrace(const DevScene &S, f3 o, f3 d, float
     for (uint32_t k = 0; k < S.n_prog; k++) {
         const ProgRec &rec = S.prog[k];
         if ((rec.op & 0xFFu) == OP_BOUND) {
-            if (rec.op & PF_FIRST) csg.reset();
+            if ((FEAT & FEAT_CSG) && (rec.op & PF_FIRST)) csg.reset();
             if (!__any(bound_hit(rec, rb, o))) {
                 k += rec.aux;
-                if (rec.op & PF_CSG) csg.push_empty();  // bound of a sub-tree inside a CSG program
+                if ((FEAT & FEAT_CSG) && (rec.op & PF_CSG)) csg.push_empty();  // bound of a sub-tree inside a CSG program
             }
             continue;
         }
@@ -649,7 +660,7 @@ __device__ __forceinline__ bool shadowtrace(const DevScene &S, f3 o, f3 d, float
         uint32_t kk, sub;
         // for meshes only hits below `limit` matter: the closest hit is either below it (and found)
         // or cannot occlude
-        if (!object_step(S, k, rec, csg, o, d, limit, lds, cnt, t, kk, sub)) continue;
+        if (!object_step<FEAT>(S, k, rec, csg, o, d, limit, lds, cnt, t, kk, sub)) continue;
         if (t > 0.0000001f && t < limit) return true;
     }
     return false;
@@ -721,6 +732,7 @@ __device__ __forceinline__ void plane_attr(const DevScene &S, uint32_t plane, ui
     }
 }
 
+template <int FEAT = FEAT_ALL>
 __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t instr_index, uint32_t sub, float t, HitAttr &h) {
     // Index guards: a winner record that is out of range means a broken invariant upstream.  Refuse it (the caller
     // sees material -1 and raises the internal-error bit) rather than fault the GPU on a wild address.
@@ -774,7 +786,7 @@ __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t
             break;
         }
         case OP_MESH: {  // triangle_object.rs:85-160 for the winning triangle only
-            if (in.aux >= S.n_meshes) return;
+            if (!(FEAT & FEAT_MESH) || in.aux >= S.n_meshes) return;
             const MeshInfo &M = S.meshes[in.aux];
             if (sub >= M.tri_count) return;
             const TriHot T = S.tris[M.tri_first + sub];

@@ -85,7 +85,7 @@ __device__ __forceinline__ uint32_t node_pixel(uint32_t g, uint32_t width, uint3
 #endif
 // MODE is a template parameter so that the raytracing-mode instance does not carry the registers of the photon
 // gather and vice versa (occupancy is VGPR-limited here).
-template <int MODE>
+template <int MODE, int FEAT>
 __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
     const DevScene &S = A.S;
     Lds lds = make_lds(A.lds_slots);
@@ -109,10 +109,10 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
             d = mk3(rd.x, rd.y, rd.z);
         }
         TraceResult tr;
-        trace(S, o, d, lds, cnt, tr);
+        trace<FEAT>(S, o, d, lds, cnt, tr);
         HitAttr h;
         if (tr.object != 0xFFFFFFFFu) {
-            eval_hit(S, o, d, tr.instr, tr.sub, tr.t, h);
+            eval_hit<FEAT>(S, o, d, tr.instr, tr.sub, tr.t, h);
             if ((uint32_t)h.material >= S.n_materials) {  // index guard of eval_hit tripped
                 cnt.overflow |= RRT_ERR_BIT_INTERNAL;
                 tr.object = 0xFFFFFFFFu;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
                     if (lit) {
                         f3 sd = -ldir;
                         f3 so = h.position + sd * 0.0001f;
-                        if (shadowtrace(S, so, sd, len3(ldir), lds, cnt)) lit = false;
+                        if (shadowtrace<FEAT>(S, so, sd, len3(ldir), lds, cnt)) lit = false;
                     }
                     f3 term = mk3(0.0f, 0.0f, 0.0f);
                     if (lit) term = material_per_light(S, M, h, viewer, ldir, cnt) * light_intensity(L, h.position);
@@ -375,10 +375,26 @@ static inline uint32_t blocks_for(uint32_t n) { return (n + RRT_BLOCK - 1) / RRT
 
 void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream) {
     if (a.count == 0) return;
-    if (a.mode == RRT_MODE_SCENE)
-        hipLaunchKernelGGL(k_trace_shade<RRT_MODE_SCENE>, dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes, stream, a);
-    else
-        hipLaunchKernelGGL(k_trace_shade<RRT_MODE_PHOTON>, dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes, stream, a);
+    // one instance per (mode, scene feature set): see SceneFeatures in dev_trace.h
+    const int feat = (a.S.has_csg ? FEAT_CSG : 0) | (a.S.n_meshes ? FEAT_MESH : 0);
+    dim3 grid(blocks_for(a.count)), block(RRT_BLOCK);
+#define RRT_LAUNCH(M, F) hipLaunchKernelGGL((k_trace_shade<M, F>), grid, block, lds_bytes, stream, a)
+    if (a.mode == RRT_MODE_SCENE) {
+        switch (feat) {
+            case 0: RRT_LAUNCH(RRT_MODE_SCENE, 0); break;
+            case FEAT_CSG: RRT_LAUNCH(RRT_MODE_SCENE, FEAT_CSG); break;
+            case FEAT_MESH: RRT_LAUNCH(RRT_MODE_SCENE, FEAT_MESH); break;
+            default: RRT_LAUNCH(RRT_MODE_SCENE, FEAT_ALL); break;
+        }
+    } else {
+        switch (feat) {
+            case 0: RRT_LAUNCH(RRT_MODE_PHOTON, 0); break;
+            case FEAT_CSG: RRT_LAUNCH(RRT_MODE_PHOTON, FEAT_CSG); break;
+            case FEAT_MESH: RRT_LAUNCH(RRT_MODE_PHOTON, FEAT_MESH); break;
+            default: RRT_LAUNCH(RRT_MODE_PHOTON, FEAT_ALL); break;
+        }
+    }
+#undef RRT_LAUNCH
 }
 void launch_combine(const TraceArgs &a, hipStream_t stream) {
     if (a.count == 0) return;
