@@ -322,6 +322,15 @@ int rrt_photon_export_device(rrt_scene *s, int which, float *pos_dev, float *inc
 int rrt_photon_import_device(rrt_scene *s, int which, const float *pos_dev, const float *incident_dev,
                              const float *intensity_dev, const uint64_t *meta_dev, uint64_t count);
 
+/* PhotonTree::get_within_distance and get_n_within_radius (core/photon_tree.rs:15-35, 41-50), batched: for each of
+ * the n query points the photons of map `which` (0 regular, 1 caustic) inside the closed cube of half width
+ * `half_width` around it, ascending by squared distance (ties by key: the reference's sort is unstable there).
+ * count[n] = photons inside the cube; key / dist2 [n][k_max] = the first min(count, k_max) of them (k_max = 0:
+ * counts only; a k_max above count leaves the rest of the row untouched).  Host pointers.  `find_nearest`
+ * (photon_tree.rs:37-39, unbounded k-NN, never called in the reference) has no counterpart yet.               */
+int rrt_photon_query(rrt_scene *s, int which, const float *positions, size_t n, float half_width, uint32_t k_max,
+                     uint32_t *count, uint64_t *key, float *dist2);
+
 /* Photon-map files: both maps of this rank (after rrt_photon_build's canonical sort order), so that cameras can be
  * re-rendered without re-shooting.  No counterpart in the reference (its maps live and die with the process);
  * SURVEY.md 8f rank 2.  Load needs rrt_photon_begin on the same scene first and rrt_photon_build after it.

@@ -1480,6 +1480,26 @@ int orc_photon_query(orc_scene *s, int which, const float p[3], float r, uint64_
     return RRT_OK;
 }
 
+// core/photon_tree.rs:15-35 (get_within_distance) + :41-50 (get_n_within_radius), by brute force over the map
+int orc_photon_query_list(orc_scene *s, int which, const float p[3], float r, uint32_t k_max, uint32_t *count, uint64_t *key, float *dist2) {
+    if (which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad map");
+    V3 pos{p[0], p[1], p[2]};
+    V3 lo = pos - V3{r, r, r}, hi = pos + V3{r, r, r};
+    std::vector<std::pair<float, uint64_t>> found;
+    for (const Photon &ph : s->env.local[which]) {
+        V3 q = ph.position;
+        if (q.x >= lo.x && q.x <= hi.x && q.y >= lo.y && q.y <= hi.y && q.z >= lo.z && q.z <= hi.z)
+            found.push_back({len_sqrd(q - pos), ph.key});  // photon_tree.rs:25
+    }
+    std::sort(found.begin(), found.end());  // by squared distance (photon_tree.rs:33); ties by key to be deterministic
+    *count = (uint32_t)found.size();
+    for (size_t i = 0; i < found.size() && i < k_max; i++) {  // truncate(n), photon_tree.rs:48
+        dist2[i] = found[i].first;
+        key[i] = found[i].second;
+    }
+    return RRT_OK;
+}
+
 // cameras/camera.rs:7-43 + full_camera.rs:93-146
 int orc_render(orc_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t y1, float *rgb, float *depth, uint32_t *object_id,
                int threads) {

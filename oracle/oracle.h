@@ -70,6 +70,11 @@ int orc_photon_import(orc_scene *s, int which, const float *pos4, const float *i
 int orc_photon_query(orc_scene *s, int which, const float p[3], float half_width, uint64_t *k,
                      float dir_sum[3], float intensity_sum[3]);
 
+/* PhotonTree::get_n_within_radius (photon_tree.rs:15-35, 41-50) for one point: photons inside the closed cube,
+ * ascending by (squared distance, key), first k_max written; returns the count inside the cube in *count */
+int orc_photon_query_list(orc_scene *s, int which, const float p[3], float half_width, uint32_t k_max, uint32_t *count, uint64_t *key,
+                          float *dist2);
+
 int orc_get_stats(const orc_scene *s, rrt_stats *out);
 
 void orc_quantise(const float *values, size_t n, uint8_t *out);

@@ -101,6 +101,7 @@ _sig("rrt_photon_caustic_export_device", C.c_int, C.c_void_p, C.c_int, C.c_void_
 _sig("rrt_photon_caustic_import_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 _sig("rrt_photon_local_count", C.c_int, C.c_void_p, C.c_int, _u64p)
 _sig("rrt_photon_export_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("rrt_photon_query", C.c_int, C.c_void_p, C.c_int, _f32p, C.c_size_t, C.c_float, C.c_uint32, _u32p, C.c_void_p, _f32p)
 _sig("rrt_photon_save", C.c_int, C.c_void_p, C.c_char_p)
 _sig("rrt_photon_load", C.c_int, C.c_void_p, C.c_char_p)
 _sig("rrt_photon_import_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -344,6 +345,17 @@ class Scene:
 
     def photon_import_device(self, which, pos4_ptr, incident4_ptr, intensity4_ptr, meta_ptr, count):
         check(lib.rrt_photon_import_device(self._h, which, pos4_ptr, incident4_ptr, intensity4_ptr, meta_ptr, count))
+
+    def photon_query(self, which, positions, half_width, k_max):
+        """PhotonTree::get_n_within_radius, batched: (count[n], key[n][k_max], dist2[n][k_max])."""
+        p = _f32(positions, (-1, 3))
+        n = p.shape[0]
+        count = np.zeros(n, np.uint32)
+        key = np.zeros((n, max(k_max, 1)), np.uint64)
+        d2 = np.full((n, max(k_max, 1)), np.inf, np.float32)
+        check(lib.rrt_photon_query(self._h, which, _fp(p), n, C.c_float(half_width), k_max, count.ctypes.data_as(_u32p),
+                                   key.ctypes.data_as(C.c_void_p), _fp(d2)))
+        return count, key[:, :k_max], d2[:, :k_max]
 
     def photon_save(self, path):
         check(lib.rrt_photon_save(self._h, str(path).encode()))

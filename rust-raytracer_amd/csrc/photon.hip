@@ -328,6 +328,48 @@ __global__ void k_strip_key(const uint64_t *meta, uint32_t n, uint64_t *key) {
     if (i < n) key[i] = meta[i] & 0x00FFFFFFFFFFFFFFull;
 }
 
+// PhotonTree::get_within_distance / get_n_within_radius (photon_tree.rs:15-50), batched: one lane per query point.
+// Photons inside the closed cube, ascending by (squared distance, key); the first k_max are written out.
+__global__ void k_photon_query(DevPhotonMap G, const uint64_t *meta, const float *positions, uint32_t n, float r, uint32_t k_max, uint32_t *count,
+                               uint64_t *key_out, float *dist2_out) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    f3 p = mk3(positions[q * 3], positions[q * 3 + 1], positions[q * 3 + 2]);
+    uint32_t found = 0;
+    if (G.count) {
+        f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);  // photon_tree.rs:16-18
+        uint32_t x0 = cell_coord(lo.x, G.inv_cell), x1 = cell_coord(hi.x, G.inv_cell);
+        uint32_t y0 = cell_coord(lo.y, G.inv_cell), y1 = cell_coord(hi.y, G.inv_cell);
+        uint32_t z0 = cell_coord(lo.z, G.inv_cell), z1 = cell_coord(hi.z, G.inv_cell);
+        uint64_t *keys = key_out + (size_t)q * k_max;
+        float *d2s = dist2_out + (size_t)q * k_max;
+        for (uint32_t cx = x0; cx <= x1; cx++)
+            for (uint32_t cy = y0; cy <= y1; cy++)
+                for (uint32_t cz = z0; cz <= z1; cz++) {
+                    uint2 range = lookup_cell(G, cell_key(cx, cy, cz));
+                    for (uint32_t i = range.x; i < range.x + range.y && i < G.count; i++) {
+                        float4 c = G.pos_cell[i];
+                        if (!(c.x >= lo.x && c.x <= hi.x && c.y >= lo.y && c.y <= hi.y && c.z >= lo.z && c.z <= hi.z)) continue;
+                        float d2 = lensq3(mk3(c.x, c.y, c.z) - p);  // (photon.position.vector() - position.vector()).len_sqrd()
+                        uint64_t key = meta[i];
+                        uint32_t have = min(found, k_max);
+                        found++;
+                        // insertion into the sorted prefix kept so far (rows are private to the lane)
+                        uint32_t at = have;
+                        while (at > 0 && (d2s[at - 1] > d2 || (d2s[at - 1] == d2 && keys[at - 1] > key))) at--;
+                        if (at >= k_max) continue;
+                        for (uint32_t m = min(have, k_max - 1); m > at; m--) {
+                            d2s[m] = d2s[m - 1];
+                            keys[m] = keys[m - 1];
+                        }
+                        d2s[at] = d2;
+                        keys[at] = key;
+                    }
+                }
+    }
+    count[q] = found;
+}
+
 static inline dim3 grid_for(uint64_t n, uint32_t block = 256) { return dim3((uint32_t)((n + block - 1) / block)); }
 
 // stable radix sort of (key, index) pairs with rocPRIM
@@ -402,6 +444,8 @@ static int build_index(rrt_scene *s, int which) {
     hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.pos.p, idx2.p, n, X.pos.p);
     hipLaunchKernelGGL(k_gather_norm, grid_for(n), dim3(256), 0, nullptr, b.dir.p, idx2.p, n, X.dir.p);
     hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.rgb.p, idx2.p, n, X.rgb.p);
+    if ((rc = X.meta.ensure(n))) return rc;
+    hipLaunchKernelGGL(k_gather<uint64_t>, grid_for(n), dim3(256), 0, nullptr, b.meta.p, idx2.p, n, X.meta.p);
     RRT_HIP(hipMemsetAsync(ncell.p, 0, 4, nullptr));
     hipLaunchKernelGGL(k_count_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, ncell.p);
     uint32_t cells = 0;
@@ -667,6 +711,36 @@ int rrt_photon_import_device(rrt_scene *s, int which, const float *pos4_dev, con
     }
     b.count = count;
     s->maps_built = false;
+    return RRT_OK;
+}
+
+int rrt_photon_query(rrt_scene *s, int which, const float *positions, size_t n, float half_width, uint32_t k_max, uint32_t *count, uint64_t *key,
+                     float *dist2) {
+    if (!s || which < 0 || which > 1 || !positions || !count) return fail(RRT_ERR_INVALID, "bad argument");
+    if (k_max && (!key || !dist2)) return fail(RRT_ERR_INVALID, "null output array");
+    if (!s->maps_built) return fail(RRT_ERR_STATE, "Photon map not built");
+    if (!(half_width >= 0.0f)) return fail(RRT_ERR_INVALID, "bad half width");
+    if (n >= (1ull << 31) || (uint64_t)n * k_max >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "query batch too large");
+    if (n == 0) return RRT_OK;
+    PhotonIndex &X = s->index[which];
+    // the cube may overlap at most a few hundred cells per axis: a larger one would scan the table for minutes
+    if (half_width * X.inv_cell > 64.0f) return fail(RRT_ERR_LIMIT, "query cube wider than 128 index cells");
+    DBuf<float> d_pos, d_d2;
+    DBuf<uint32_t> d_count;
+    DBuf<uint64_t> d_key;
+    int rc;
+    size_t rows = (size_t)n * k_max;
+    if ((rc = d_pos.ensure(n * 3)) || (rc = d_count.ensure(n)) || (rc = d_key.ensure(rows ? rows : 1)) || (rc = d_d2.ensure(rows ? rows : 1))) return rc;
+    RRT_HIP(hipMemcpy(d_pos.p, positions, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_photon_query, grid_for(n, 64), dim3(64), 0, nullptr, X.view(), X.meta.p, d_pos.p, (uint32_t)n, half_width, k_max, d_count.p,
+                       d_key.p, d_d2.p);
+    RRT_HIP(hipGetLastError());
+    RRT_HIP(hipDeviceSynchronize());
+    RRT_HIP(hipMemcpy(count, d_count.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (rows) {
+        RRT_HIP(hipMemcpy(key, d_key.p, rows * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        RRT_HIP(hipMemcpy(dist2, d_d2.p, rows * sizeof(float), hipMemcpyDeviceToHost));
+    }
     return RRT_OK;
 }
 

@@ -85,6 +85,7 @@ struct PhotonBuffers {
 };
 struct PhotonIndex {
     DBuf<float4> pos, dir, rgb;
+    DBuf<uint64_t> meta;  // record keys in cell order (only the query entry point reads them)
     DBuf<uint64_t> keys;
     DBuf<uint2> ranges;
     uint32_t table_size = 0;

@@ -67,6 +67,7 @@ _sig("orc_photon_caustic_export", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _u
 _sig("orc_photon_caustic_import", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _u64p, C.c_uint64)
 _sig("orc_photon_export", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _f32p, _u64p)
 _sig("orc_photon_import", C.c_int, C.c_void_p, C.c_int, _f32p, _f32p, _f32p, _u64p, C.c_uint64)
+_sig("orc_photon_query_list", C.c_int, C.c_void_p, C.c_int, _f32p, C.c_float, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, _f32p)
 _sig("orc_photon_query", C.c_int, C.c_void_p, C.c_int, _f32p, C.c_float, _u64p, _f32p, _f32p)
 _sig("orc_get_stats", C.c_int, C.c_void_p, C.POINTER(abi.Stats))
 _sig("orc_quantise", None, _f32p, C.c_size_t, _u8p)
@@ -288,6 +289,19 @@ class OracleScene:
         pos, inc, rgb = _f32(pos, (-1, 4)), _f32(inc, (-1, 4)), _f32(rgb, (-1, 4))
         meta = np.ascontiguousarray(meta, np.uint64)
         check(lib.orc_photon_import(self._h, which, _fp(pos), _fp(inc), _fp(rgb), meta.ctypes.data_as(_u64p), pos.shape[0]))
+
+    def photon_query_list(self, which, positions, half_width, k_max):
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        n = p.shape[0]
+        count = np.zeros(n, np.uint32)
+        key = np.zeros((n, max(k_max, 1)), np.uint64)
+        d2 = np.full((n, max(k_max, 1)), np.inf, np.float32)
+        for i in range(n):
+            c = C.c_uint32(0)
+            check(lib.orc_photon_query_list(self._h, which, _fp(p[i]), C.c_float(half_width), k_max, C.byref(c),
+                                            key[i].ctypes.data_as(C.c_void_p), _fp(d2[i])))
+            count[i] = c.value
+        return count, key[:, :k_max], d2[:, :k_max]
 
     def photon_query(self, which, p, half_width):
         p = _f32(p)

@@ -160,6 +160,37 @@ def test_index_finds_exactly_the_photons_in_the_closed_cube(repo):
     assert k_brute > 0
 
 
+def test_photon_query_matches_get_n_within_radius(repo):
+    """rrt_photon_query = PhotonTree::get_within_distance / get_n_within_radius (photon_tree.rs:15-50), batched, against the
+    oracle's brute force over the same map: counts, squared distances (bit-exact) and photon keys."""
+    cpu, gpu, cam = pair(repo, "pm_caustics", 60000, 2000)
+    with pytest.raises(rrt.RrtError) as e:
+        gpu.photon_query(0, [[0, 0, 0]], 0.1, 4)
+    assert e.value.code == abi.ERR_STATE        # "Photon map not built"
+    cpu.pre_render(11)
+    gpu.pre_render(11)
+    cam.width = cam.height = 24
+    rays = [rrt.camera_ray(cam, x, y) for y in range(0, 24, 2) for x in range(0, 24, 2)]
+    hit = cpu.trace([r[0] for r in rays], [r[1] for r in rays])
+    pts = hit["position"][hit["object_id"] != abi.MISS]
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([pts, pts + rng.normal(0, 0.05, pts.shape).astype(np.float32), rng.uniform(-3, 3, (40, 3)).astype(np.float32)])
+    assert len(pts) > 150
+    for which in (0, 1):
+        for half_width, k_max in ((0.1, 16), (0.1, 0), (0.25, 7), (0.033, 64)):   # the index's own cell size and others
+            cg, kg, dg = gpu.photon_query(which, pts, half_width, k_max)
+            cc, kc, dc = cpu.photon_query_list(which, pts, half_width, k_max)
+            assert np.array_equal(cg, cc)
+            for i in range(len(pts)):
+                m = min(int(cc[i]), k_max)
+                assert np.array_equal(bits(dg[i, :m]), bits(dc[i, :m])), (which, half_width, i)
+                assert np.array_equal(kg[i, :m], kc[i, :m]), (which, half_width, i)
+                assert np.all(np.diff(dc[i, :m]) >= 0)
+        # the regular map really is queried where photons are
+        if which == 0:
+            assert gpu.photon_query(0, pts, 0.1, 0)[0].max() > 20
+
+
 def test_scene2_at_the_reference_settings_matches_the_committed_render(repo):
     """render/rgb.ppm is one unseeded photon-mapped run of scene2 (5 M + 10 k photons, 1024^2) with the author's
     ffmpeg-decoded textures; render/rgb.png, a second run, differs from it by MAE 1.87/255, PSNR 37.05 dB
