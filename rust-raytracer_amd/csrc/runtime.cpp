@@ -370,6 +370,8 @@ int flatten_scene(rrt_scene *s) {
             }
         }
     }
+    for (const ProgRec &r : F.prog)  // sub-tree bounds inside a CSG program count too, not only whole-object bounds
+        if ((r.op & 0xFFu) == OP_BOUND) has_bounds = true;
     if (getenv("RRT_DUMP_PROGRAM")) {  // debugging aid: the record stream, without touching the device
         static const char *names[] = {"plane", "sphere", "cuboid", "quadric", "mesh", "union", "intersection", "difference", "bound"};
         for (size_t k = 0; k < F.prog.size(); k++) {

@@ -148,3 +148,60 @@ def teapot_grid(obj_pos, obj_nrm, nx, ny, spacing=30.0):
             if obj_nrm is not None:
                 outn.append(np.asarray(obj_nrm, np.float32).reshape(-1, 3, 3))
     return np.concatenate(outs), (np.concatenate(outn) if outn else None)
+
+
+def random_scene(scene, seed, with_mesh=True):
+    """A deterministic random scene out of every primitive, CSG trees up to depth 3, per-object transforms and an optional
+    small triangle soup; the same call sequence builds the product scene and the oracle scene."""
+    rng = np.random.default_rng(seed)
+    u = lambda lo, hi, n=None: rng.uniform(lo, hi, n).astype(np.float32) if n else np.float32(rng.uniform(lo, hi))
+    mats = [monochrome(scene, tuple(u(0.1, 1.0, 3)), 0.1, 50.0) for _ in range(3)]
+    mats.append(compound(scene, [monochrome(scene, (0.5, 0.5, 0.8)), global_material(scene, 0.5, 0.0, 1.0)]))
+    mats.append(compound(scene, [monochrome(scene, (0.2, 0.3, 0.2)), global_material(scene, 0.8, 0.8, 1.4)]))
+
+    def primitive(allow_plane=True):
+        kind = rng.integers(0, 5 if allow_plane else 4)
+        m = mats[rng.integers(0, len(mats))]
+        c = u(-2.0, 2.0, 3)
+        if kind == 0:
+            return sphere(scene, tuple(c), float(u(0.3, 1.2)), m)
+        if kind == 1:
+            return cuboid(scene, tuple(c - 0.5), tuple(u(0.3, 1.8, 3)), m)
+        if kind == 2:  # ellipsoid / cylinder / paraboloid-like quadrics around the origin, moved by the transform below
+            q = np.zeros(10, np.float32)
+            q[0], q[4], q[7] = u(0.5, 4.0), u(0.0, 4.0) * rng.integers(0, 2), u(0.5, 4.0)
+            q[9] = -u(0.3, 1.5)
+            if rng.integers(0, 4) == 0:
+                q[6] = u(-0.5, 0.5)
+            h = quadric(scene, tuple(q), m)
+            scene.object_transform(h, translation(tuple(c)))
+            return h
+        if kind == 3:
+            return sphere(scene, tuple(c), float(u(0.2, 0.6)), m)
+        n = u(-1.0, 1.0, 3)
+        n /= np.linalg.norm(n)
+        up = np.cross(n, u(-1.0, 1.0, 3)).astype(np.float32)
+        up /= np.linalg.norm(up)
+        return plane(scene, tuple(u(-2.5, -1.0, 3)), tuple(up), tuple(n), m)
+
+    def tree(depth):
+        if depth == 0 or rng.integers(0, 3) == 0:
+            return primitive(allow_plane=rng.integers(0, 6) == 0)
+        mode = int(rng.integers(0, 3))
+        return csg(scene, mode, tree(depth - 1), tree(depth - 1))
+
+    for _ in range(int(rng.integers(4, 9))):
+        h = tree(int(rng.integers(0, 4)))
+        t = rng.integers(0, 3)
+        if t == 1:
+            scene.object_transform(h, translation(tuple(u(-1.0, 1.0, 3))))
+        elif t == 2:
+            scene.object_transform(h, scaling(float(u(0.6, 1.6))))
+        scene.add_object(h)
+    if with_mesh and rng.integers(0, 2) == 0:
+        n_tri = int(rng.integers(8, 60))
+        base = u(-2.0, 2.0, (n_tri, 1, 3))
+        tris = base + u(-0.6, 0.6, (n_tri, 3, 3))
+        scene.add_object(mesh(scene, tris, None, mats[0], False))
+    light(scene, abi.LIGHT_POINT, position=tuple(u(-4.0, 4.0, 3)), colour=(1.0, 1.0, 1.0))
+    return scene

@@ -18,6 +18,7 @@ static size_t g_lds_elems = 0;
         }                                                                                                                \
     } while (0)
 #include "dev_trace.h"
+#include <barrier>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -99,58 +100,65 @@ int main(int argc, char **argv) {
     uint32_t overflow = 0;
     std::mutex om;
     const int W = 64;
-    for (size_t base = 0; base < n; base += W) {
-        int lanes = (int)std::min<size_t>(W, n - base);
-        // exact-size heap arrays: ASan flags any entry or slot index out of range
-        // ONE buffer, laid out and sized as runtime.cpp does for a 256-thread block (lists and BVH stack alias);
-        // the wave emulated here plays lanes 64..127 of that block.  Filled with garbage, as on the device.
-        const uint32_t BLOCK = 256;
-        size_t list_bytes = (size_t)misc[0] * 6 * BLOCK * 8, stack_bytes = (size_t)((misc[1] + 1) / 2) * BLOCK * 8;
-        g_lds_elems = std::max(list_bytes, stack_bytes) / 8;
-        std::vector<float2> lists(g_lds_elems, float2{1.5f, __uint_as_float(0xFFFFFFFFu)});
-        Wave wave, sync;
-        std::vector<std::thread> th;
-        for (int phase = 0; phase < 2; phase++) {
-            wave.join_all(lanes);
-            th.clear();
-            for (int lane = 0; lane < lanes; lane++)
-                th.emplace_back([&, lane, phase] {
-                    tl_wave = &wave;
-                    size_t i = base + lane;
-                    Lds lds; lds.le = lists.data(); lds.stack = reinterpret_cast<int *>(lists.data()); lds.nthreads = BLOCK; lds.tid = 64u + (uint32_t)lane;
-                    Counters cnt = {0, 0, 0, 0};
-                    f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
-                    if (phase == 0) {
-                        TraceResult tr;
-                        trace(S, o, d, lds, cnt, tr);
-                        results[i * 4] = tr.object;
-                        results[i * 4 + 1] = __float_as_uint(tr.object == 0xFFFFFFFFu ? 0.0f : tr.t);
-                        uint32_t prim = 0;  // as k_batch_trace computes it
-                        if (tr.object != 0xFFFFFFFFu) {
-                            const ProgRec &in = S.prog[tr.instr];
-                            uint32_t op = in.op & 0xFFu;
-                            if (op == OP_MESH) {
-                                prim = S.tri_index[S.meshes[in.aux].tri_first + tr.sub];
-                            } else if (in.op & PF_CSG) {
-                                for (uint32_t k = tr.instr; !(S.prog[k].op & PF_FIRST);) {
-                                    k--;
-                                    if ((S.prog[k].op & 0xFFu) < OP_CSG_UNION) prim++;
-                                }
-                            } else if (op == OP_CUBOID) {
-                                prim = tr.sub;
-                                if (in.aux + (tr.sub >> 1) >= plane_cold.size()) abort();
-                            }
-                        }
-                        results[i * 4 + 2] = prim;
-                    } else {
-                        results[i * 4 + 3] = shadowtrace(S, o, d, 6.0f, lds, cnt) ? 1u : 0u;
+    // 64 lane threads live for the whole run; a std::barrier separates waves and phases (trace, then shadowtrace)
+    const uint32_t BLOCK = 256;
+    size_t list_bytes = (size_t)misc[0] * 6 * BLOCK * 8, stack_bytes = (size_t)((misc[1] + 1) / 2) * BLOCK * 8;
+    g_lds_elems = std::max(list_bytes, stack_bytes) / 8;
+    // ONE buffer, laid out and sized as runtime.cpp does for a 256-thread block (lists and BVH stack alias); the wave
+    // emulated here plays lanes 64..127 of that block.  Refilled with garbage for every wave, as on the device.
+    std::vector<float2> lists(std::max<size_t>(g_lds_elems, 1));
+    Wave wave;
+    std::barrier<> phase_sync(W);
+    std::vector<std::thread> th;
+    for (int lane = 0; lane < W; lane++)
+        th.emplace_back([&, lane] {
+            tl_wave = &wave;
+            for (size_t base = 0; base < n; base += W) {
+                int lanes = (int)std::min<size_t>(W, n - base);
+                for (int phase = 0; phase < 2; phase++) {
+                    if (lane == 0) {
+                        wave.join_all(lanes);
+                        if (phase == 0) std::fill(lists.begin(), lists.end(), float2{1.5f, __uint_as_float(0xFFFFFFFFu)});
                     }
-                    wave.leave();
-                    if (cnt.overflow) { std::lock_guard<std::mutex> g(om); overflow |= cnt.overflow; }
-                });
-            for (auto &t : th) t.join();
-        }
-    }
+                    phase_sync.arrive_and_wait();
+                    if (lane < lanes) {
+                        size_t i = base + lane;
+                        Lds lds; lds.le = lists.data(); lds.stack = reinterpret_cast<int *>(lists.data()); lds.nthreads = BLOCK; lds.tid = 64u + (uint32_t)lane;
+                        Counters cnt = {0, 0, 0, 0};
+                        f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+                        if (phase == 0) {
+                            TraceResult tr;
+                            trace(S, o, d, lds, cnt, tr);
+                            results[i * 4] = tr.object;
+                            results[i * 4 + 1] = __float_as_uint(tr.object == 0xFFFFFFFFu ? 0.0f : tr.t);
+                            uint32_t prim = 0;  // as k_batch_trace computes it
+                            if (tr.object != 0xFFFFFFFFu) {
+                                const ProgRec &in = S.prog[tr.instr];
+                                uint32_t op = in.op & 0xFFu;
+                                if (op == OP_MESH) {
+                                    prim = S.tri_index[S.meshes[in.aux].tri_first + tr.sub];
+                                } else if (in.op & PF_CSG) {
+                                    for (uint32_t k = tr.instr; !(S.prog[k].op & PF_FIRST);) {
+                                        k--;
+                                        if ((S.prog[k].op & 0xFFu) < OP_CSG_UNION) prim++;
+                                    }
+                                } else if (op == OP_CUBOID) {
+                                    prim = tr.sub;
+                                    if (in.aux + (tr.sub >> 1) >= plane_cold.size()) abort();
+                                }
+                            }
+                            results[i * 4 + 2] = prim;
+                        } else {
+                            results[i * 4 + 3] = shadowtrace(S, o, d, 6.0f, lds, cnt) ? 1u : 0u;
+                        }
+                        wave.leave();
+                        if (cnt.overflow) { std::lock_guard<std::mutex> g(om); overflow |= cnt.overflow; }
+                    }
+                    phase_sync.arrive_and_wait();
+                }
+            }
+        });
+    for (auto &t : th) t.join();
     FILE *out = fopen(argv[3], "wb");
     fwrite(results.data(), 4, results.size(), out);
     fclose(out);
