@@ -37,8 +37,13 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 }
 __device__ __forceinline__ void flush_counters(const Counters &cnt, unsigned long long gathered, unsigned long long queries,
                                                unsigned long long candidates, unsigned long long *stats, uint32_t *err) {
+#ifdef RRT_PROBE_NOSTATS
+    if (cnt.overflow) atomicOr(err, cnt.overflow);
+    return;
+#endif
     unsigned long long n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), s = wave_sum(cnt.shadow);
     unsigned long long g = wave_sum(gathered), q = wave_sum(queries), c = wave_sum(candidates);
+    stats += (blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE;
     if ((threadIdx.x & 63) == 0) {
         if (n) atomicAdd(&stats[ST_NODES], n);
         if (t) atomicAdd(&stats[ST_TRIS], t);
@@ -194,15 +199,48 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
         }
     }
 
-    // ---- wave-compacted append of the child rays to the next level's queue ----
+    // ---- append of the child rays to the next level's queue, and the statistics: ONE atomic per block each ----
+    // Per wave a 64-bit ballot + lane-prefix popcount gives each lane its slot inside the wave's share; the four waves'
+    // shares are laid end to end through LDS and thread 0 reserves the block's total with a single atomicAdd (one
+    // atomic per wave on the one queue counter serialises in the L2: 32 k waves at 1080p).
+    __shared__ uint32_t s_wave_total[RRT_BLOCK / 64];
+    __shared__ uint32_t s_block_base;
+    __shared__ unsigned long long s_stat[RRT_BLOCK / 64][ST_COUNT];
+    __shared__ uint32_t s_err;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
     uint32_t total = __popcll(ma) + __popcll(mb);
+    {
+        unsigned long long v[ST_COUNT] = {cnt.nodes, cnt.tris, cnt.shadow, gathered, queries, candidates};
+#pragma unroll
+        for (int k = 0; k < ST_COUNT; k++) v[k] = wave_sum(v[k]);
+        if (threadIdx.x == 0) s_err = 0;
+        if (lane == 0) {
+            s_wave_total[wave] = total;
+#pragma unroll
+            for (int k = 0; k < ST_COUNT; k++) s_stat[wave][k] = v[k];
+        }
+    }
+    __syncthreads();
+    if (cnt.overflow) atomicOr(&s_err, cnt.overflow);
+    if (threadIdx.x < ST_COUNT) {  // thread k owns statistic k
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int w = 0; w < RRT_BLOCK / 64; w++) sum += s_stat[w][threadIdx.x];
+        if (sum) atomicAdd(&A.stats[(blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE + threadIdx.x], sum);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t block_total = 0;
+#pragma unroll
+        for (int w = 0; w < RRT_BLOCK / 64; w++) block_total += s_wave_total[w];
+        s_block_base = block_total ? atomicAdd(A.next_count, block_total) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_err) atomicOr(A.err, s_err);
     int2 child = make_int2(-1, -1);
     if (total) {
-        uint32_t lane = threadIdx.x & 63;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(A.next_count, total);
-        base = __shfl(base, 0, 64);
+        uint32_t base = s_block_base;
+        for (uint32_t w = 0; w < wave; w++) base += s_wave_total[w];
         if (base + total > A.next_limit) {  // prediction too small: the host repeats the frame level by level
             if (lane == 0) atomicOr(A.err, RRT_ERR_BIT_QUEUE);
             want_a = want_b = false;
@@ -222,7 +260,6 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
         }
     }
     if (active) A.cur.child[i] = child;
-    flush_counters(cnt, gathered, queries, candidates, A.stats, A.err);
 }
 
 __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {

@@ -257,8 +257,9 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
         t += __shfl_xor(t, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (n) atomicAdd(&A.stats[ST_NODES], n);
-        if (t) atomicAdd(&A.stats[ST_TRIS], t);
+        unsigned long long *stats = A.stats + (blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE;
+        if (n) atomicAdd(&stats[ST_NODES], n);
+        if (t) atomicAdd(&stats[ST_TRIS], t);
     }
     err |= cnt.overflow;
     if (err) atomicOr(A.err, err);
@@ -531,7 +532,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         uint32_t init[2] = {(uint32_t)s->local[0].count, (uint32_t)s->local[1].count};
         RRT_HIP(hipMemcpy(counts.p, init, sizeof(init), hipMemcpyHostToDevice));
         RRT_HIP(hipMemset(s->counters.p + 63, 0, 4));
-        RRT_HIP(hipMemset(s->stats_dev.p, 0, ST_COUNT * sizeof(unsigned long long)));
+        RRT_HIP(hipMemset(s->stats_dev.p, 0, RRT_STAT_WORDS * sizeof(unsigned long long)));
         ShootArgs A;
         memset(&A, 0, sizeof(A));
         A.S = s->dev.view;
@@ -579,7 +580,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         s->local[0].count = got[0];
         s->local[1].count = got[1];
         unsigned long long st[ST_COUNT];
-        RRT_HIP(hipMemcpy(st, s->stats_dev.p, sizeof(st), hipMemcpyDeviceToHost));
+        if ((rc = read_stats(s, st))) return rc;
         s->stats.bvh_nodes_visited = st[ST_NODES];
         s->stats.bvh_tris_tested = st[ST_TRIS];
         if (pass == 0) {

@@ -498,12 +498,22 @@ int flatten_scene(rrt_scene *s) {
 int ensure_workspace(rrt_scene *s) {
     int rc;
     if ((rc = s->counters.ensure(64))) return rc;
-    if ((rc = s->stats_dev.ensure(ST_COUNT))) return rc;
-    if (!s->host_pinned) RRT_HIP(hipHostMalloc((void **)&s->host_pinned, 64 * sizeof(uint32_t)));
+    if ((rc = s->stats_dev.ensure(RRT_STAT_WORDS))) return rc;
+    if (!s->host_pinned) RRT_HIP(hipHostMalloc((void **)&s->host_pinned, RRT_STAT_WORDS * sizeof(unsigned long long)));
     while (s->events.size() < 4) {
         hipEvent_t e;
         RRT_HIP(hipEventCreate(&e));
         s->events.push_back(e);
+    }
+    return RRT_OK;
+}
+
+int read_stats(rrt_scene *s, unsigned long long out[ST_COUNT]) {
+    std::vector<unsigned long long> all(RRT_STAT_WORDS);
+    RRT_HIP(hipMemcpy(all.data(), s->stats_dev.p, RRT_STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < ST_COUNT; k++) {
+        out[k] = 0;
+        for (int c = 0; c < RRT_STAT_COPIES; c++) out[k] += all[c * RRT_STAT_STRIDE + k];
     }
     return RRT_OK;
 }
@@ -591,12 +601,12 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     for (uint32_t j = 0; j < want_lanes; j++)
         if (s->lanes[j]->levels.size() < n_levels + 1) s->lanes[j]->levels.resize(n_levels + 1);
 
-    RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, ST_COUNT * sizeof(unsigned long long), stream));
+    RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, RRT_STAT_WORDS * sizeof(unsigned long long), stream));
     RRT_HIP(hipEventRecord(s->events[0], stream));
     uint64_t secondary = 0;
     float ms_trace = 0.0f;
     uint32_t err = 0;
-    unsigned long long *st = reinterpret_cast<unsigned long long *>(s->host_pinned);  // 64 words = room for ST_COUNT slots
+    unsigned long long *st_all = reinterpret_cast<unsigned long long *>(s->host_pinned);  // RRT_STAT_WORDS slots
     bool tail_done = false;
 
     for (uint32_t round_base = 0; round_base < n_pixels;) {
@@ -667,7 +677,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
             }
             if (round_base >= n_pixels) {  // last round: the frame's end event and the stats ride on the same sync
                 RRT_HIP(hipEventRecord(s->events[1], stream));
-                RRT_HIP(hipMemcpyAsync(st, s->stats_dev.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                RRT_HIP(hipMemcpyAsync(st_all, s->stats_dev.p, RRT_STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
                 tail_done = true;
             }
             RRT_HIP(hipStreamSynchronize(stream));
@@ -756,8 +766,13 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     }
     if (!tail_done) {
         RRT_HIP(hipEventRecord(s->events[1], stream));
-        RRT_HIP(hipMemcpyAsync(st, s->stats_dev.p, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        RRT_HIP(hipMemcpyAsync(st_all, s->stats_dev.p, RRT_STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         RRT_HIP(hipStreamSynchronize(stream));
+    }
+    unsigned long long st[ST_COUNT];
+    for (int k = 0; k < ST_COUNT; k++) {
+        st[k] = 0;
+        for (int c = 0; c < RRT_STAT_COPIES; c++) st[k] += st_all[c * RRT_STAT_STRIDE + k];
     }
     float ms_total = 0.0f;
     RRT_HIP(hipEventElapsedTime(&ms_total, s->events[0], s->events[1]));
@@ -1101,7 +1116,7 @@ static int batch_common(rrt_scene *s, const float *origins, const float *directi
     A.err = s->counters.p + 63;
     A.stats = s->stats_dev.p;
     RRT_HIP(hipMemset(s->counters.p, 0, 64 * sizeof(uint32_t)));
-    RRT_HIP(hipMemset(s->stats_dev.p, 0, ST_COUNT * sizeof(unsigned long long)));
+    RRT_HIP(hipMemset(s->stats_dev.p, 0, RRT_STAT_WORDS * sizeof(unsigned long long)));
     if (shadow) {
         if (!limits || !occluded) return fail(RRT_ERR_INVALID, "null argument");
         if ((rc = d_lim.ensure(n)) || (rc = d_occ.ensure(n))) return rc;
@@ -1126,7 +1141,7 @@ static int batch_common(rrt_scene *s, const float *origins, const float *directi
     uint32_t err = 0;
     RRT_HIP(hipMemcpy(&err, s->counters.p + 63, sizeof(err), hipMemcpyDeviceToHost));
     unsigned long long st[ST_COUNT];
-    RRT_HIP(hipMemcpy(st, s->stats_dev.p, sizeof(st), hipMemcpyDeviceToHost));
+    if ((rc = read_stats(s, st))) return rc;
     s->stats.bvh_nodes_visited = st[ST_NODES];
     s->stats.bvh_tris_tested = st[ST_TRIS];
     if (err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");

@@ -155,6 +155,8 @@ struct rrt_scene {
 namespace rrt {
 int flatten_scene(rrt_scene *s);
 int ensure_workspace(rrt_scene *s);
+// sums the RRT_STAT_COPIES device-side copies of the counters (synchronous)
+int read_stats(rrt_scene *s, unsigned long long out[ST_COUNT]);
 int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
                 const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream);
 void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth);
