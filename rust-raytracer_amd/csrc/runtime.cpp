@@ -16,7 +16,7 @@ rrt_scene::~rrt_scene() {
         if (L->ev_trace0) (void)hipEventDestroy(L->ev_trace0);
         if (L->ev_trace1) (void)hipEventDestroy(L->ev_trace1);
         if (L->ev_done) (void)hipEventDestroy(L->ev_done);
-        if (L->host_pinned) (void)hipHostFree(L->host_pinned);
+        if (L->host_pinned && L->owns_pinned) (void)hipHostFree(L->host_pinned);
     }
 }
 
@@ -498,8 +498,10 @@ int flatten_scene(rrt_scene *s) {
 int ensure_workspace(rrt_scene *s) {
     int rc;
     if ((rc = s->counters.ensure(64))) return rc;
-    if ((rc = s->stats_dev.ensure(RRT_STAT_WORDS))) return rc;
-    if (!s->host_pinned) RRT_HIP(hipHostMalloc((void **)&s->host_pinned, RRT_STAT_WORDS * sizeof(unsigned long long)));
+    // lane 0's 64 queue counters live right behind the statistics (device and pinned host copies alike), so that one
+    // memset clears both at the start of a frame and one copy brings both back at its end
+    if ((rc = s->stats_dev.ensure(RRT_STAT_WORDS + 32))) return rc;
+    if (!s->host_pinned) RRT_HIP(hipHostMalloc((void **)&s->host_pinned, (RRT_STAT_WORDS + 32) * sizeof(unsigned long long)));
     while (s->events.size() < 4) {
         hipEvent_t e;
         RRT_HIP(hipEventCreate(&e));
@@ -538,9 +540,16 @@ int ensure_lanes(rrt_scene *s, uint32_t n) {
         s->lanes.emplace_back(new RenderLane());
         RenderLane &L = *s->lanes.back();
         int rc;
-        if ((rc = L.counters.ensure(64))) return rc;
-        RRT_HIP(hipHostMalloc((void **)&L.host_pinned, 64 * sizeof(uint32_t)));
-        if (s->lanes.size() > 1) RRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        if (s->lanes.size() == 1) {  // lane 0 borrows the tail of the statistics buffers (see ensure_workspace)
+            L.ctr = reinterpret_cast<uint32_t *>(s->stats_dev.p + RRT_STAT_WORDS);
+            L.host_pinned = s->host_pinned + 2 * RRT_STAT_WORDS;
+        } else {
+            if ((rc = L.counters.ensure(64))) return rc;
+            L.ctr = L.counters.p;
+            RRT_HIP(hipHostMalloc((void **)&L.host_pinned, 64 * sizeof(uint32_t)));
+            L.owns_pinned = true;
+            RRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        }
         RRT_HIP(hipEventCreate(&L.ev_trace0));
         RRT_HIP(hipEventCreate(&L.ev_trace1));
         RRT_HIP(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
@@ -568,7 +577,7 @@ void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, ui
     A.band_rows = cam && cam->width ? n_pixels / cam->width : 0;
     A.lds_slots = D.lds_slots;
     A.gather_half_width = s->params.gather_half_width;
-    A.err = L.counters.p + 63;
+    A.err = L.ctr + 63;
     A.stats = s->stats_dev.p;
     A.out_rgb = rgb_dev;
     A.out_depth = depth_dev;
@@ -601,7 +610,8 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     for (uint32_t j = 0; j < want_lanes; j++)
         if (s->lanes[j]->levels.size() < n_levels + 1) s->lanes[j]->levels.resize(n_levels + 1);
 
-    RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, RRT_STAT_WORDS * sizeof(unsigned long long), stream));
+    RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, (RRT_STAT_WORDS + 32) * sizeof(unsigned long long), stream));  // + lane 0's counters
+    bool lane0_clean = true;
     RRT_HIP(hipEventRecord(s->events[0], stream));
     uint64_t secondary = 0;
     float ms_trace = 0.0f;
@@ -644,7 +654,8 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     if ((rc = L.levels[k].ensure(caps[k], n_lights, true))) return rc;
                 }
                 if ((rc = L.levels[n_levels].ensure(1, n_lights, true))) return rc;
-                RRT_HIP(hipMemsetAsync(L.counters.p, 0, 64 * sizeof(uint32_t), st));
+                if (!(j == 0 && lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), st));
+                if (j == 0) lane0_clean = false;
                 if (!cam)
                     launch_load_rays(origins_dev + (size_t)plan[j].base * 3, directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), st);
                 TraceArgs A;
@@ -654,10 +665,10 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     A.cur = L.levels[k].view();
                     A.next = L.levels[k + 1].view();
                     A.count = caps[k];
-                    A.count_ptr = k ? L.counters.p + k : nullptr;
+                    A.count_ptr = k ? L.ctr + k : nullptr;
                     A.next_limit = caps[k + 1];
                     A.level = k;
-                    A.next_count = L.counters.p + (k + 1);
+                    A.next_count = L.ctr + (k + 1);
                     launch_trace_shade(A, D.lds_bytes, st);
                 }
                 RRT_HIP(hipEventRecord(L.ev_trace1, st));
@@ -665,11 +676,12 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     A.cur = L.levels[k].view();
                     A.next = L.levels[k + 1].view();
                     A.count = caps[k];
-                    A.count_ptr = k ? L.counters.p + k : nullptr;
+                    A.count_ptr = k ? L.ctr + k : nullptr;
                     A.level = (uint32_t)k;
                     launch_combine(A, st);
                 }
-                RRT_HIP(hipMemcpyAsync(L.host_pinned, L.counters.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                const bool one_copy = plan.size() == 1 && round_base >= n_pixels;  // statistics + counters in one go below
+                if (!one_copy) RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 if (j > 0) {  // join
                     RRT_HIP(hipEventRecord(L.ev_done, st));
                     RRT_HIP(hipStreamWaitEvent(stream, L.ev_done, 0));
@@ -677,7 +689,8 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
             }
             if (round_base >= n_pixels) {  // last round: the frame's end event and the stats ride on the same sync
                 RRT_HIP(hipEventRecord(s->events[1], stream));
-                RRT_HIP(hipMemcpyAsync(st_all, s->stats_dev.p, RRT_STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                RRT_HIP(hipMemcpyAsync(st_all, s->stats_dev.p, (RRT_STAT_WORDS + (plan.size() == 1 ? 32 : 0)) * sizeof(unsigned long long),
+                                       hipMemcpyDeviceToHost, stream));
                 tail_done = true;
             }
             RRT_HIP(hipStreamSynchronize(stream));
@@ -708,7 +721,8 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                 RenderLane &L = *s->lanes[j];
                 std::vector<uint32_t> &counts = plan[j].counts;
                 if ((rc = L.levels[0].ensure(plan[j].n, n_lights, cam == nullptr))) return rc;
-                RRT_HIP(hipMemsetAsync(L.counters.p, 0, 64 * sizeof(uint32_t), stream));
+                if (!(j == 0 && lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), stream));
+                if (j == 0) lane0_clean = false;
                 if (!cam)
                     launch_load_rays(origins_dev + (size_t)plan[j].base * 3, directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), stream);
                 TraceArgs A;
@@ -723,14 +737,14 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     A.count_ptr = nullptr;
                     A.next_limit = spawns ? 2 * counts[k] : 0;
                     A.level = k;
-                    A.next_count = L.counters.p + (k + 1);
+                    A.next_count = L.ctr + (k + 1);
                     RRT_HIP(hipEventRecord(L.ev_trace0, stream));
                     launch_trace_shade(A, D.lds_bytes, stream);
                     RRT_HIP(hipEventRecord(L.ev_trace1, stream));
                     last = k;
                     uint32_t next_n = 0;
                     if (spawns) {
-                        RRT_HIP(hipMemcpyAsync(L.host_pinned, L.counters.p + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                        RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                         RRT_HIP(hipStreamSynchronize(stream));
                         next_n = L.host_pinned[0];
                     } else {
@@ -751,7 +765,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     A.level = (uint32_t)k;
                     launch_combine(A, stream);
                 }
-                RRT_HIP(hipMemcpyAsync(L.host_pinned, L.counters.p + 63, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr + 63, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 RRT_HIP(hipStreamSynchronize(stream));
                 err |= L.host_pinned[0];
             }

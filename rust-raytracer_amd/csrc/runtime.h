@@ -114,8 +114,10 @@ namespace rrt {
 // caller's stream; the others on streams of their own, forked from and joined to the caller's stream with events.
 struct RenderLane {
     std::vector<LevelStorage> levels;
-    DBuf<uint32_t> counters;  // [k] = rays queued for level k, [63] = error bits
+    DBuf<uint32_t> counters;  // lanes > 0 own their counters; lane 0 borrows the tail of the statistics buffer
+    uint32_t *ctr = nullptr;  // [k] = rays queued for level k, [63] = error bits
     uint32_t *host_pinned = nullptr;
+    bool owns_pinned = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev_trace0 = nullptr, ev_trace1 = nullptr, ev_done = nullptr;
     std::vector<uint32_t> prediction;  // [0] = chunk size it was measured on, [1 + k] = size of level k
