@@ -203,7 +203,7 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
     // Per wave a 64-bit ballot + lane-prefix popcount gives each lane its slot inside the wave's share; the four waves'
     // shares are laid end to end through LDS and thread 0 reserves the block's total with a single atomicAdd (one
     // atomic per wave on the one queue counter serialises in the L2: 32 k waves at 1080p).
-    __shared__ uint32_t s_wave_total[RRT_BLOCK / 64];
+    __shared__ uint32_t s_wave_a[RRT_BLOCK / 64], s_wave_b[RRT_BLOCK / 64];
     __shared__ uint32_t s_block_base;
     __shared__ unsigned long long s_stat[RRT_BLOCK / 64][ST_COUNT];
     __shared__ uint32_t s_err;
@@ -216,7 +216,8 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
         for (int k = 0; k < ST_COUNT; k++) v[k] = wave_sum(v[k]);
         if (threadIdx.x == 0) s_err = 0;
         if (lane == 0) {
-            s_wave_total[wave] = total;
+            s_wave_a[wave] = __popcll(ma);
+            s_wave_b[wave] = __popcll(mb);
 #pragma unroll
             for (int k = 0; k < ST_COUNT; k++) s_stat[wave][k] = v[k];
         }
@@ -232,31 +233,41 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
     if (threadIdx.x == 0) {
         uint32_t block_total = 0;
 #pragma unroll
-        for (int w = 0; w < RRT_BLOCK / 64; w++) block_total += s_wave_total[w];
+        for (int w = 0; w < RRT_BLOCK / 64; w++) block_total += s_wave_a[w] + s_wave_b[w];
         s_block_base = block_total ? atomicAdd(A.next_count, block_total) : 0u;
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_err) atomicOr(A.err, s_err);
     int2 child = make_int2(-1, -1);
     if (total) {
-        uint32_t base = s_block_base;
-        for (uint32_t w = 0; w < wave; w++) base += s_wave_total[w];
-        if (base + total > A.next_limit) {  // prediction too small: the host repeats the frame level by level
+        // the block's reflection rays first, then its refraction rays: a wave of the next level then holds one kind of
+        // ray from one 8x8-tile neighbourhood, which keeps its rays together at the bound boxes
+        uint32_t all_a = 0, base_a = s_block_base, base_b = s_block_base;
+        for (uint32_t w = 0; w < RRT_BLOCK / 64; w++) {
+            all_a += s_wave_a[w];
+            if (w < wave) {
+                base_a += s_wave_a[w];
+                base_b += s_wave_b[w];
+            }
+        }
+        base_b += all_a;
+        unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+        uint32_t off_a = base_a + __popcll(ma & below), off_b = base_b + __popcll(mb & below);
+        uint32_t block_end = s_block_base;
+        for (uint32_t w = 0; w < RRT_BLOCK / 64; w++) block_end += s_wave_a[w] + s_wave_b[w];
+        if (block_end > A.next_limit) {  // prediction too small: the host repeats the frame level by level
             if (lane == 0) atomicOr(A.err, RRT_ERR_BIT_QUEUE);
             want_a = want_b = false;
         }
-        unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-        uint32_t off = base + __popcll(ma & below) + __popcll(mb & below);
         if (want_a) {
-            child.x = (int)off;
-            A.next.ray_o[off] = make_float4(ao.x, ao.y, ao.z, __uint_as_float(i));
-            A.next.ray_d[off] = make_float4(ad.x, ad.y, ad.z, __uint_as_float(0u));
-            off++;
+            child.x = (int)off_a;
+            A.next.ray_o[off_a] = make_float4(ao.x, ao.y, ao.z, __uint_as_float(i));
+            A.next.ray_d[off_a] = make_float4(ad.x, ad.y, ad.z, __uint_as_float(0u));
         }
         if (want_b) {
-            child.y = (int)off;
-            A.next.ray_o[off] = make_float4(bo.x, bo.y, bo.z, __uint_as_float(i));
-            A.next.ray_d[off] = make_float4(bd.x, bd.y, bd.z, __uint_as_float(1u));
+            child.y = (int)off_b;
+            A.next.ray_o[off_b] = make_float4(bo.x, bo.y, bo.z, __uint_as_float(i));
+            A.next.ray_d[off_b] = make_float4(bd.x, bd.y, bd.z, __uint_as_float(1u));
         }
     }
     if (active) A.cur.child[i] = child;
