@@ -99,7 +99,9 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> results(n * 4);
     uint32_t overflow = 0;
     std::mutex om;
-    const int W = 64;
+    // wave width: 64 as on the device; 1 makes every ray its own wave, so each bound decides for that ray alone (the
+    // strictest check of the skip logic)
+    const int W = getenv("EMU_WAVE") ? atoi(getenv("EMU_WAVE")) : 64;
     // 64 lane threads live for the whole run; a std::barrier separates waves and phases (trace, then shadowtrace)
     const uint32_t BLOCK = 256;
     size_t list_bytes = (size_t)misc[0] * 6 * BLOCK * 8, stack_bytes = (size_t)((misc[1] + 1) / 2) * BLOCK * 8;
@@ -123,7 +125,7 @@ int main(int argc, char **argv) {
                     phase_sync.arrive_and_wait();
                     if (lane < lanes) {
                         size_t i = base + lane;
-                        Lds lds; lds.le = lists.data(); lds.stack = reinterpret_cast<int *>(lists.data()); lds.nthreads = BLOCK; lds.tid = 64u + (uint32_t)lane;
+                        Lds lds; lds.le = lists.data(); lds.stack = reinterpret_cast<int *>(lists.data()); lds.nthreads = BLOCK; lds.tid = (64u + (uint32_t)lane) % BLOCK;
                         Counters cnt = {0, 0, 0, 0};
                         f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
                         if (phase == 0) {
