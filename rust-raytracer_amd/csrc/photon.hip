@@ -26,11 +26,18 @@ namespace rrt {
 #define RRT_BLOCK 256
 extern __shared__ float4 g_smem_ph[];
 
+// Records are appended with one atomic per wave and store call.  A single counter per buffer serialises in the L2
+// (same-address atomics: ~4 ns each, tens of them per wave and bounce), so a call writes into PH_SEGMENTS staging
+// segments, each with its own counter on its own cache line and picked by block index; k_compact_photons then copies
+// the segments end to end behind the records the buffer already holds.  The order records land in is irrelevant:
+// the index build sorts them by key.
+#define PH_SEGMENTS 64
+#define PH_COUNT_STRIDE 16  // counters 64 bytes apart
 struct PhotonOut {
     float4 *pos, *dir, *rgb;
     uint64_t *meta;
-    uint32_t *count;
-    uint32_t capacity;
+    uint32_t *count;        // [PH_SEGMENTS * PH_COUNT_STRIDE]
+    uint32_t seg_capacity;  // records per segment
 };
 
 struct ShootArgs {
@@ -63,12 +70,14 @@ __device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter) {
 }
 
 __device__ __forceinline__ void store_photon(const PhotonOut &o, bool want, f3 p, f3 d, f3 c, uint32_t type, uint64_t meta, uint32_t &err) {
-    uint32_t slot = wave_append(want, o.count);
+    const uint32_t seg = blockIdx.x % PH_SEGMENTS;
+    uint32_t slot = wave_append(want, o.count + seg * PH_COUNT_STRIDE);
     if (!want) return;
-    if (slot >= o.capacity) {
+    if (slot >= o.seg_capacity) {
         err |= PH_ERR_CAPACITY;
         return;
     }
+    slot += seg * o.seg_capacity;
     o.pos[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(type));
     o.dir[slot] = make_float4(d.x, d.y, d.z, 0.0f);
     o.rgb[slot] = make_float4(c.x, c.y, c.z, 0.0f);
@@ -371,6 +380,21 @@ __global__ void k_photon_query(DevPhotonMap G, const uint64_t *meta, const float
     count[q] = found;
 }
 
+struct SegmentPrefix {
+    uint32_t count[PH_SEGMENTS], first[PH_SEGMENTS];
+};
+// staging segments -> contiguous records behind dst_base
+__global__ void k_compact_photons(PhotonOut src, SegmentPrefix P, float4 *pos, float4 *dir, float4 *rgb, uint64_t *meta, uint64_t dst_base) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t seg = i / src.seg_capacity, l = i - seg * src.seg_capacity;
+    if (seg >= PH_SEGMENTS || l >= P.count[seg]) return;
+    uint64_t to = dst_base + P.first[seg] + l;
+    pos[to] = src.pos[i];
+    dir[to] = src.dir[i];
+    rgb[to] = src.rgb[i];
+    meta[to] = src.meta[i];
+}
+
 static inline dim3 grid_for(uint64_t n, uint32_t block = 256) { return dim3((uint32_t)((n + block - 1) / block)); }
 
 // stable radix sort of (key, index) pairs with rocPRIM
@@ -518,31 +542,35 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         return RRT_OK;
     }
     int rc;
-    DBuf<uint32_t> counts;
-    if ((rc = counts.ensure(2))) return rc;
+    PhotonScratch &W = s->photon_scratch;
+    if ((rc = W.seg_counts.ensure(2 * PH_SEGMENTS * PH_COUNT_STRIDE))) return rc;
     double est[2] = {pass == 0 ? 4.0 : 0.0, pass == 0 ? 1.0 : 5.0};
     hipEvent_t e0 = s->events[0], e1 = s->events[1];
-    for (int attempt = 0; attempt < 8; attempt++) {
-        uint64_t need[2];
+    uint64_t got[2] = {0, 0};
+    for (int attempt = 0;; attempt++) {
+        if (attempt == 8) return fail(RRT_ERR_LIMIT, "photon staging buffers kept overflowing");
+        uint32_t seg_cap[2];
         for (int w = 0; w < 2; w++) {
-            need[w] = s->local[w].count + (uint64_t)(est[w] * (double)count) + 4096;
-            if (need[w] >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
-            if ((rc = grow_photons(s->local[w], need[w]))) return rc;
+            uint64_t per_seg = (uint64_t)(est[w] * (double)count * 1.3 / PH_SEGMENTS) + 512;
+            if (per_seg * PH_SEGMENTS >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
+            seg_cap[w] = (uint32_t)per_seg;
+            size_t n = (size_t)per_seg * PH_SEGMENTS;
+            if ((rc = W.stage[w].pos.ensure(n)) || (rc = W.stage[w].dir.ensure(n)) || (rc = W.stage[w].rgb.ensure(n)) || (rc = W.stage[w].meta.ensure(n)))
+                return rc;
         }
-        uint32_t init[2] = {(uint32_t)s->local[0].count, (uint32_t)s->local[1].count};
-        RRT_HIP(hipMemcpy(counts.p, init, sizeof(init), hipMemcpyHostToDevice));
+        RRT_HIP(hipMemset(W.seg_counts.p, 0, 2 * PH_SEGMENTS * PH_COUNT_STRIDE * sizeof(uint32_t)));
         RRT_HIP(hipMemset(s->counters.p + 63, 0, 4));
         RRT_HIP(hipMemset(s->stats_dev.p, 0, RRT_STAT_WORDS * sizeof(unsigned long long)));
         ShootArgs A;
         memset(&A, 0, sizeof(A));
         A.S = s->dev.view;
         for (int w = 0; w < 2; w++) {
-            A.out[w].pos = s->local[w].pos.p;
-            A.out[w].dir = s->local[w].dir.p;
-            A.out[w].rgb = s->local[w].rgb.p;
-            A.out[w].meta = s->local[w].meta.p;
-            A.out[w].count = counts.p + w;
-            A.out[w].capacity = (uint32_t)std::min<uint64_t>(s->local[w].pos.cap, 0xFFFFFFFFull);
+            A.out[w].pos = W.stage[w].pos.p;
+            A.out[w].dir = W.stage[w].dir.p;
+            A.out[w].rgb = W.stage[w].rgb.p;
+            A.out[w].meta = W.stage[w].meta.p;
+            A.out[w].count = W.seg_counts.p + w * PH_SEGMENTS * PH_COUNT_STRIDE;
+            A.out[w].seg_capacity = seg_cap[w];
         }
         A.seed_pos = cs.pos.p;
         A.seed_dir = cs.dir.p;
@@ -558,23 +586,47 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         A.stats = s->stats_dev.p;
         RRT_HIP(hipEventRecord(e0, nullptr));
         hipLaunchKernelGGL(k_photon_shoot, grid_for(count, RRT_BLOCK), dim3(RRT_BLOCK), s->dev.lds_bytes, nullptr, A);
+        RRT_HIP(hipGetLastError());
+        uint32_t err = 0;
+        std::vector<uint32_t> raw(2 * PH_SEGMENTS * PH_COUNT_STRIDE);
+        RRT_HIP(hipMemcpy(&err, s->counters.p + 63, 4, hipMemcpyDeviceToHost));
+        RRT_HIP(hipMemcpy(raw.data(), W.seg_counts.p, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");
+        if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
+        if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
+        if (err & 4u) return fail(RRT_ERR_LIMIT, "more than 63 shadow photons behind one landing");
+        SegmentPrefix P[2];
+        bool overflow = (err & PH_ERR_CAPACITY) != 0;
+        for (int w = 0; w < 2; w++) {
+            uint64_t total = 0, worst = 0;
+            for (int g = 0; g < PH_SEGMENTS; g++) {
+                uint32_t c = raw[(w * PH_SEGMENTS + g) * PH_COUNT_STRIDE];  // counts what the segment was ASKED to hold
+                worst = std::max<uint64_t>(worst, c);
+                if (c > seg_cap[w]) overflow = true;
+                P[w].count[g] = std::min(c, seg_cap[w]);
+                P[w].first[g] = (uint32_t)total;
+                total += P[w].count[g];
+            }
+            got[w] = total;
+            if (overflow) est[w] = std::max(est[w] * 1.5, 1.25 * (double)(worst * PH_SEGMENTS) / (double)count);
+        }
+        if (overflow) continue;  // rerun with room for what this attempt wanted to store
+        for (int w = 0; w < 2; w++) {
+            PhotonBuffers &b = s->local[w];
+            if (b.count + got[w] >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
+            if ((rc = grow_photons(b, b.count + got[w] + 1))) return rc;
+            if (got[w])
+                hipLaunchKernelGGL(k_compact_photons, grid_for((uint64_t)seg_cap[w] * PH_SEGMENTS), dim3(256), 0, nullptr, A.out[w], P[w], b.pos.p, b.dir.p,
+                                   b.rgb.p, b.meta.p, (uint64_t)b.count);
+        }
         RRT_HIP(hipEventRecord(e1, nullptr));
         RRT_HIP(hipGetLastError());
         RRT_HIP(hipDeviceSynchronize());
         float ms = 0.0f;
         RRT_HIP(hipEventElapsedTime(&ms, e0, e1));
-        uint32_t err = 0, got[2];
-        RRT_HIP(hipMemcpy(&err, s->counters.p + 63, 4, hipMemcpyDeviceToHost));
-        RRT_HIP(hipMemcpy(got, counts.p, sizeof(got), hipMemcpyDeviceToHost));
-        if (err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");
-        if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
-        if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
-        if (err & 4u) return fail(RRT_ERR_LIMIT, "more than 63 shadow photons behind one landing");
-        if (err & PH_ERR_CAPACITY) {  // rerun with room for what this attempt wanted to store
-            for (int w = 0; w < 2; w++) est[w] = std::max(est[w] * 1.5, 1.25 * (double)(got[w] - init[w]) / (double)count);
-            continue;
-        }
-        s->stats.ms_photon_shoot += ms;
+        got[0] += s->local[0].count;
+        got[1] += s->local[1].count;
+        s->stats.ms_photon_shoot += ms;  // shooting kernel + compaction
         s->stats.photons_emitted += count;
         uint64_t caustic_before = s->local[1].count;
         s->local[0].count = got[0];

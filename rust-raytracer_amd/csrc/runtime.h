@@ -100,6 +100,8 @@ struct PhotonScratch {
     DBuf<uint64_t> keys, keys2;
     DBuf<float4> t;
     DBuf<uint8_t> sort_temp;
+    PhotonBuffers stage[2];    // segmented staging of one rrt_photon_shoot call (photon.hip)
+    DBuf<uint32_t> seg_counts;
 };
 struct CausticSeeds {
     DBuf<float4> pos, dir;
