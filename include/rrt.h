@@ -55,7 +55,7 @@ typedef struct rrt_params {
     uint32_t chunk_pixels;              /* pixels per wavefront-queue chunk (0 = default 1<<22)     */
     uint32_t render_streams;            /* HIP streams the chunks of a frame are spread over (0 or 1 =
                                            the caller's stream only, the default; at most 8).  Measured
-                                           on MI355X: 2 / 4 / 8 streams are 7 / 17 / 70 % slower on the
+                                           on MI355X: 2 / 4 / 8 streams are 9 / 21 / 100 % slower on the
                                            1080p CSG scene, so this is off by default      */
     uint32_t reserved[8];
 } rrt_params;
