@@ -137,6 +137,22 @@ def random_rays(n, seed, origin_scale=6.0, towards=(0.0, 1.0, 4.0), spread=4.0):
     return o.astype(np.float32), d.astype(np.float32)
 
 
+def coherent_rays(n, seed, origin_scale=6.0, towards=(0.0, 1.0, 4.0), spread=4.0, cone=0.08):
+    """Rays in bundles of 64 that share an origin (up to a small jitter) and aim into a narrow cone around a common
+    target: what camera tiles and shadow rays of one surface patch look like.  Exercises the wave-level object cull."""
+    rng = np.random.default_rng(seed)
+    nb = (n + 63) // 64
+    bo = (rng.random((nb, 1, 3), dtype=np.float32) - 0.5) * 2 * origin_scale
+    bt = np.asarray(towards, np.float32) + (rng.random((nb, 1, 3), dtype=np.float32) - 0.5) * 2 * spread
+    jitter = np.where(rng.random((nb, 1, 1)) < 0.5, 0.0, 0.05).astype(np.float32)
+    o = bo + (rng.random((nb, 64, 3), dtype=np.float32) - 0.5) * jitter
+    dist = np.linalg.norm(bt - bo, axis=2, keepdims=True)
+    t = bt + (rng.random((nb, 64, 3), dtype=np.float32) - 0.5) * 2 * cone * dist
+    d = t - o
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    return o.reshape(-1, 3)[:n].astype(np.float32), d.reshape(-1, 3)[:n].astype(np.float32)
+
+
 def teapot_grid(obj_pos, obj_nrm, nx, ny, spacing=30.0):
     """Deterministic big mesh: an nx x ny grid of copies of a base mesh (BASELINE config 4 generator)."""
     pos = np.asarray(obj_pos, np.float32).reshape(-1, 3, 3)

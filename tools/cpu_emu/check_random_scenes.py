@@ -21,7 +21,8 @@ for seed in range(first, first + count):
         if e.code != abi.ERR_DEVICE:
             print("seed", seed, "flatten refused:", e); continue
     cpu = kit.random_scene(ob.OracleScene(), seed)
-    o, d = kit.random_rays(int(os.environ.get("EMU_RAYS", "2000")), seed, origin_scale=5.0, towards=(0.0, 0.0, 0.0), spread=3.0)
+    make_rays = kit.coherent_rays if os.environ.get("EMU_COHERENT") else kit.random_rays   # coherent: the wave cull bites
+    o, d = make_rays(int(os.environ.get("EMU_RAYS", "2000")), seed, origin_scale=5.0, towards=(0.0, 0.0, 0.0), spread=3.0)
     np.concatenate([o, d], axis=1).astype(np.float32).tofile(os.path.join(tmp, "rays.f32"))
     r = subprocess.run([emu, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "rays.f32"), os.path.join(tmp, "out.bin")], capture_output=True, text=True)
     if r.returncode:

@@ -18,6 +18,7 @@ static size_t g_lds_elems = 0;
         }                                                                                                                \
     } while (0)
 #include "dev_trace.h"
+#include <atomic>
 #include <barrier>
 #include <condition_variable>
 #include <mutex>
@@ -29,9 +30,12 @@ struct Wave {
     std::condition_variable cv;
     int active = 0, arrived = 0;
     bool acc = false, result = false;
+    unsigned long long bits = 0, bits_result = 0;
     uint64_t gen = 0;
     void complete() {
         result = acc;
+        bits_result = bits;
+        bits = 0;
         acc = false;
         arrived = 0;
         gen++;
@@ -51,6 +55,20 @@ struct Wave {
         }
         return result;
     }
+    unsigned long long ballot(bool x, int lane) {
+        std::unique_lock<std::mutex> l(m);
+        if (x) bits |= 1ULL << lane;
+        if (++arrived == active) {
+            complete();
+            return bits_result;
+        }
+        uint64_t g = gen;
+        if (!cv.wait_for(l, std::chrono::seconds(20), [&] { return gen != g; })) {
+            fprintf(stderr, "DEADLOCK: lanes disagree on the sequence of wave collectives\n");
+            abort();
+        }
+        return bits_result;
+    }
     void leave() {  // lane returns from the call
         std::unique_lock<std::mutex> l(m);
         active--;
@@ -64,7 +82,12 @@ struct Wave {
     }
 };
 static thread_local Wave *tl_wave = nullptr;
+static thread_local int tl_lane = 0;
 bool __any(bool x) { return tl_wave->any(x); }
+unsigned long long __ballot(bool x) { return tl_wave->ballot(x, tl_lane); }
+void emu_wave_sync() { (void)tl_wave->any(false); }
+static std::atomic<long long> g_cull_visited{0}, g_cull_total{0};
+void emu_cull_stat(int visited, int total) { g_cull_visited += visited; g_cull_total += total; }
 template <class T> static std::vector<T> get(FILE *f) {
     uint64_t hdr[2];
     if (fread(hdr, sizeof(hdr), 1, f) != 1) { fprintf(stderr, "short file\n"); exit(2); }
@@ -109,12 +132,14 @@ int main(int argc, char **argv) {
     // ONE buffer, laid out and sized as runtime.cpp does for a 256-thread block (lists and BVH stack alias); the wave
     // emulated here plays lanes 64..127 of that block.  Refilled with garbage for every wave, as on the device.
     std::vector<float2> lists(std::max<size_t>(g_lds_elems, 1));
+    const float shadow_limit = getenv("EMU_SHADOW_LIMIT") ? (float)atof(getenv("EMU_SHADOW_LIMIT")) : 6.0f;
     Wave wave;
     std::barrier<> phase_sync(W);
     std::vector<std::thread> th;
     for (int lane = 0; lane < W; lane++)
         th.emplace_back([&, lane] {
             tl_wave = &wave;
+            tl_lane = lane;
             for (size_t base = 0; base < n; base += W) {
                 int lanes = (int)std::min<size_t>(W, n - base);
                 for (int phase = 0; phase < 2; phase++) {
@@ -151,7 +176,7 @@ int main(int argc, char **argv) {
                             }
                             results[i * 4 + 2] = prim;
                         } else {
-                            results[i * 4 + 3] = shadowtrace(S, o, d, 6.0f, lds, cnt) ? 1u : 0u;
+                            results[i * 4 + 3] = shadowtrace(S, o, d, shadow_limit, lds, cnt) ? 1u : 0u;
                         }
                         wave.leave();
                         if (cnt.overflow) { std::lock_guard<std::mutex> g(om); overflow |= cnt.overflow; }
@@ -165,5 +190,6 @@ int main(int argc, char **argv) {
     fwrite(results.data(), 4, results.size(), out);
     fclose(out);
     fprintf(stderr, "%zu rays, overflow %u\n", n, overflow);
+    if (g_cull_total) fprintf(stderr, "object visits after the wave cull: %.1f %% of lane-objects\n", 100.0 * (double)g_cull_visited / (double)std::max<long long>(1, g_cull_total));
     return 0;
 }
