@@ -421,6 +421,7 @@ static int grow_preserve(DBuf<T> &b, size_t need, size_t used) {
 }
 static int grow_photons(PhotonBuffers &b, uint64_t need) {
     int rc;
+    if (need > b.pos.cap && b.pos.cap) need = std::max<uint64_t>(need, b.pos.cap + b.pos.cap / 2);  // repeated appends: amortised copies
     if ((rc = grow_preserve(b.pos, need, b.count)) || (rc = grow_preserve(b.dir, need, b.count)) || (rc = grow_preserve(b.rgb, need, b.count)) ||
         (rc = grow_preserve(b.meta, need, b.count)))
         return rc;
@@ -475,6 +476,7 @@ static int build_index(rrt_scene *s, int which) {
     hipLaunchKernelGGL(k_count_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, ncell.p);
     uint32_t cells = 0;
     RRT_HIP(hipMemcpy(&cells, ncell.p, 4, hipMemcpyDeviceToHost));
+    if (cells >= (1u << 30)) return fail(RRT_ERR_LIMIT, "photon index above 2^30 occupied cells");
     uint32_t size = 64;
     while (size < 2 * cells) size <<= 1;
     if ((rc = X.keys.ensure(size)) || (rc = X.ranges.ensure(size))) return rc;
@@ -552,7 +554,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         uint32_t seg_cap[2];
         for (int w = 0; w < 2; w++) {
             uint64_t per_seg = (uint64_t)(est[w] * (double)count * 1.3 / PH_SEGMENTS) + 512;
-            if (per_seg * PH_SEGMENTS >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
+            if (per_seg * PH_SEGMENTS >= (1ull << 32) - 4096) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
             seg_cap[w] = (uint32_t)per_seg;
             size_t n = (size_t)per_seg * PH_SEGMENTS;
             if ((rc = W.stage[w].pos.ensure(n)) || (rc = W.stage[w].dir.ensure(n)) || (rc = W.stage[w].rgb.ensure(n)) || (rc = W.stage[w].meta.ensure(n)))
@@ -613,7 +615,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         if (overflow) continue;  // rerun with room for what this attempt wanted to store
         for (int w = 0; w < 2; w++) {
             PhotonBuffers &b = s->local[w];
-            if (b.count + got[w] >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
+            if (b.count + got[w] >= (1ull << 32) - 4096) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
             if ((rc = grow_photons(b, b.count + got[w] + 1))) return rc;
             if (got[w])
                 hipLaunchKernelGGL(k_compact_photons, grid_for((uint64_t)seg_cap[w] * PH_SEGMENTS), dim3(256), 0, nullptr, A.out[w], P[w], b.pos.p, b.dir.p,

@@ -1050,10 +1050,17 @@ int rrt_pre_render(rrt_scene *s, uint64_t seed) {
     if (s->mode == RRT_MODE_PHOTON) {
         int rc = rrt_photon_begin(s, seed);
         if (rc) return rc;
-        for (int l = 0; l < (int)s->lights.size(); l++) {
-            if ((rc = rrt_photon_shoot(s, l, 0, 0, s->params.photons_per_light))) return rc;
-            if ((rc = rrt_photon_shoot(s, l, 1, 0, s->params.caustic_photons_per_light))) return rc;
-        }
+        // Big passes go in index ranges (streams are keyed by photon index and the maps are sorted into canonical
+        // order before the index build, so the split changes no bit): bounds the staging buffers to a few GB at the
+        // 100 M photons of BASELINE configs[4].
+        uint64_t step = 1ull << 24;
+        if (const char *e = getenv("RRT_SHOOT_CHUNK")) step = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        for (int l = 0; l < (int)s->lights.size(); l++)
+            for (int pass = 0; pass < 2; pass++) {
+                const uint64_t total = pass == 0 ? s->params.photons_per_light : s->params.caustic_photons_per_light;
+                for (uint64_t first = 0; first < total; first += step)
+                    if ((rc = rrt_photon_shoot(s, l, pass, first, std::min(step, total - first)))) return rc;
+            }
         return rrt_photon_build(s);
     }
     s->seed = seed;

@@ -83,6 +83,20 @@ def test_photon_pass_is_deterministic_and_split_independent(repo):
     assert not np.array_equal(c.photon_read(0)["position"][:1000], a.photon_read(0)["position"][:1000])
 
 
+def test_pre_render_in_index_ranges_changes_nothing(repo, monkeypatch):
+    """rrt_pre_render shoots big passes in photon-index ranges (2^24 at a time; RRT_SHOOT_CHUNK overrides): same maps."""
+    _, a, cam = pair(repo, "pm_caustics", 30000, 2000)
+    _, b, _ = pair(repo, "pm_caustics", 30000, 2000)
+    a.pre_render(3)
+    monkeypatch.setenv("RRT_SHOOT_CHUNK", "7001")
+    b.pre_render(3)
+    assert b.stats()["photons_emitted"] == 32000
+    for which in (0, 1):
+        pa, pb = a.photon_read(which), b.photon_read(which)
+        for k in pa:
+            assert np.array_equal(pa[k].view(np.uint8), pb[k].view(np.uint8)), (which, k)
+
+
 def test_device_exchange_round_trip(repo):
     """The multi-GPU exchange points with one rank: export -> import -> build gives the same frame."""
     import importlib
