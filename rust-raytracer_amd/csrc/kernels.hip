@@ -37,10 +37,6 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 }
 __device__ __forceinline__ void flush_counters(const Counters &cnt, unsigned long long gathered, unsigned long long queries,
                                                unsigned long long candidates, unsigned long long *stats, uint32_t *err) {
-#ifdef RRT_PROBE_NOSTATS
-    if (cnt.overflow) atomicOr(err, cnt.overflow);
-    return;
-#endif
     unsigned long long n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), s = wave_sum(cnt.shadow);
     unsigned long long g = wave_sum(gathered), q = wave_sum(queries), c = wave_sum(candidates);
     stats += (blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE;
