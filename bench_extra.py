@@ -52,10 +52,10 @@ def teapot_grid(nx=13, nz=13, spacing=34.0):
     return np.ascontiguousarray(np.concatenate(P), np.float32), np.ascontiguousarray(np.concatenate(N), np.float32)
 
 
-def build_mesh_scene(rrt, smooth=True):
+def build_mesh_scene(rrt, smooth=True, bvh_builder=0):
     abi = rrt._abi
     pos, nrm = teapot_grid()
-    s = rrt.Scene()
+    s = rrt.Scene(params=rrt.default_params(bvh_builder=bvh_builder))
     m = abi.MaterialDesc()
     m.kind = abi.MAT_MONOCHROME
     m.colour[:] = (0.8, 0.6, 0.2)
@@ -89,9 +89,9 @@ def build_mesh_scene(rrt, smooth=True):
     return s, cam, pos.shape[0]
 
 
-def run_mesh(rrt, torch, steps=5):
+def run_mesh(rrt, torch, steps=5, bvh_builder=0):
     t0 = time.perf_counter()
-    scene, cam, ntri = build_mesh_scene(rrt)
+    scene, cam, ntri = build_mesh_scene(rrt, bvh_builder=bvh_builder)
     t_build_host = time.perf_counter() - t0
     t0 = time.perf_counter()
     scene.pre_render(1)
@@ -123,6 +123,8 @@ def run_mesh(rrt, torch, steps=5):
         "hit_fraction": float((ids >= 0).float().mean().item()),
         "bvh_nodes_per_ray": st["bvh_nodes_visited"] / (st["rays_primary"] + st["rays_shadow"]),
         "bvh_tris_per_ray": st["bvh_tris_tested"] / (st["rays_primary"] + st["rays_shadow"]),
+        "bvh_builder": "device LBVH" if bvh_builder else "host binned SAH",
+        "ms_bvh_build": st["ms_bvh_build"],
         "host_seconds": {"mesh_generation": t_build_host, "pre_render_incl_bvh_build": t_pre},
         "roofline": {"kernel": "k_trace_shade", "bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "kernel_ms_per_frame": kernel_ms / steps},
@@ -201,6 +203,8 @@ if __name__ == "__main__":
     res = {}
     if which in ("all", "mesh"):
         res["mesh_1m"] = run_mesh(rrt, torch)
+    if which in ("all", "mesh_lbvh"):
+        res["mesh_1m_device_lbvh"] = run_mesh(rrt, torch, bvh_builder=1)
     if which in ("all", "photon"):
         res["photon_1m"] = run_photon(rrt, torch)
     print(json.dumps(res, indent=1))

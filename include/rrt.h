@@ -57,8 +57,13 @@ typedef struct rrt_params {
                                            the caller's stream only, the default; at most 8).  Measured
                                            on MI355X: 2 / 4 / 8 streams are 9 / 21 / 100 % slower on the
                                            1080p CSG scene, so this is off by default      */
-    uint32_t reserved[8];
+    uint32_t bvh_builder;               /* RRT_BVH_HOST_SAH (0, default): binned-SAH build on the host, the faster trees;
+                                           RRT_BVH_DEVICE_LBVH (1): Morton-order build on the GPU for meshes of more
+                                           than 4 triangles (rebuilds in milliseconds; same frames, slower traversal).
+                                           The reference has no acceleration structure (polymesh_object.rs:219-236) */
+    uint32_t reserved[7];
 } rrt_params;
+enum rrt_bvh_builder { RRT_BVH_HOST_SAH = 0, RRT_BVH_DEVICE_LBVH = 1 };
 
 /* ---- materials (src/materials) ------------------------------------------------------ */
 enum rrt_material_kind {
@@ -157,7 +162,8 @@ typedef struct rrt_stats {
     uint64_t flops_per_trace;    /* analytic-primitive flops one trace() of this scene costs           */
     uint64_t frames_repeated;    /* render calls since rrt_pre_render that were run twice because a level
                                     queue outgrew the size predicted from the previous frame */
-    uint64_t reserved[5];
+    double ms_bvh_build;         /* rrt_pre_render: time spent building mesh BVHs (host wall clock, whichever builder) */
+    uint64_t reserved[4];
 } rrt_stats;
 
 /* ---- builder vtable --------------------------------------------------------------------

@@ -11,6 +11,9 @@ LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_DIRPOINT = range(3)
 MISS = 0xFFFFFFFF
 
 
+BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
+
+
 class Params(C.Structure):
     _fields_ = [
         ("photons_per_light", C.c_uint32),
@@ -21,7 +24,8 @@ class Params(C.Structure):
         ("max_vueon_depth", C.c_uint32),
         ("chunk_pixels", C.c_uint32),
         ("render_streams", C.c_uint32),
-        ("reserved", C.c_uint32 * 8),
+        ("bvh_builder", C.c_uint32),
+        ("reserved", C.c_uint32 * 7),
     ]
 
 
@@ -98,7 +102,8 @@ class Stats(C.Structure):
         ("flops_algorithmic", C.c_uint64),
         ("flops_per_trace", C.c_uint64),
         ("frames_repeated", C.c_uint64),
-        ("reserved", C.c_uint64 * 5),
+        ("ms_bvh_build", C.c_double),
+        ("reserved", C.c_uint64 * 4),
     ]
 
     def as_dict(self):

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 using namespace rrt;
 
@@ -81,6 +82,9 @@ struct Flat {
     std::vector<BvhNode> nodes;
     uint32_t bvh_depth = 0;
     uint64_t flops = 0;
+    uint32_t bvh_builder = RRT_BVH_HOST_SAH;
+    int error = RRT_OK;       // first failure inside emit (device BVH build)
+    double ms_bvh_build = 0;  // host wall clock
 };
 
 uint32_t add_plane(Flat &F, f3 point, f3 up, f3 normal, float d, int material) {
@@ -238,7 +242,17 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
             std::vector<uint32_t> order;
             std::vector<BvhNode> nodes;
             uint32_t depth = 0;
-            build_bvh(o.tri_pos.data(), n, order, nodes, depth);
+            auto t0 = std::chrono::steady_clock::now();
+            if (F.bvh_builder == RRT_BVH_DEVICE_LBVH && n > 4) {
+                int rc = build_bvh_device(o.tri_pos.data(), n, order, nodes, depth, nullptr);
+                if (rc) {
+                    if (!F.error) F.error = rc;
+                    break;
+                }
+            } else {
+                build_bvh(o.tri_pos.data(), n, order, nodes, depth);
+            }
+            F.ms_bvh_build += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             F.bvh_depth = std::max(F.bvh_depth, depth);
             mi.node_count = (uint32_t)nodes.size();
             F.nodes.insert(F.nodes.end(), nodes.begin(), nodes.end());
@@ -336,6 +350,8 @@ int flatten_materials(rrt_scene *s, std::vector<DevMaterial> &out, bool &reflect
 
 int flatten_scene(rrt_scene *s) {
     Flat F;
+    if (s->params.bvh_builder > RRT_BVH_DEVICE_LBVH) return fail(RRT_ERR_INVALID, "unknown bvh_builder");
+    F.bvh_builder = s->params.bvh_builder;
     g_bounds_enabled = getenv("RRT_NO_BOUNDS") == nullptr;  // debugging aid: the reference's plain all-objects loop
     uint32_t max_stack = 0;
     bool has_csg = false, has_bounds = false;
@@ -350,6 +366,7 @@ int flatten_scene(rrt_scene *s) {
         }
         uint32_t first = (uint32_t)F.prog.size();
         emit(F, ho, bb);
+        if (F.error) return F.error;  // rrt_last_error holds the message
         uint32_t count = (uint32_t)F.prog.size() - first;
         if (bound_rec >= 0) F.prog[bound_rec].aux = count;
         for (uint32_t k = 0; k < count; k++) F.prog[first + k].object = (uint32_t)oi;
@@ -492,6 +509,7 @@ int flatten_scene(rrt_scene *s) {
     V.texels16 = D.texels16.p;
     V.lights = D.lights.p;
     s->flattened = true;
+    s->stats.ms_bvh_build = F.ms_bvh_build;
     return ensure_workspace(s);
 }
 

@@ -164,6 +164,9 @@ int read_stats(rrt_scene *s, unsigned long long out[ST_COUNT]);
 int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
                 const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream);
 void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth);
+// bvh_lbvh.hip: the same outputs from the device-side LBVH build (n > 4); device_ms = HIP-event time of its kernels
+int build_bvh_device(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
+                     float *device_ms);
 int read_ppm(const std::string &path, HostTexture &tex);
 int load_obj(const std::string &path, bool smooth, std::vector<float> &tri_pos, std::vector<float> &tri_nrm);
 }  // namespace rrt

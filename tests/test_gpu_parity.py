@@ -240,8 +240,8 @@ def adversarial_rays(pos, n, seed):
     return np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32)
 
 
-def mesh_pair(pos, nrm, smooth):
-    cpu, gpu = ob.OracleScene(), rrt.Scene()
+def mesh_pair(pos, nrm, smooth, builder=abi.BVH_HOST_SAH):
+    cpu, gpu = ob.OracleScene(), rrt.Scene(params=rrt.default_params(bvh_builder=builder))
     for s in (cpu, gpu):
         s.add_object(kit.mesh(s, pos, nrm, kit.falsecolour(s), smooth))
     gpu.pre_render(1)
@@ -263,24 +263,67 @@ def load_teapot(repo, name="teapot.obj"):
     return test_host_side.python_obj_loader(os.path.join(repo, "assets/models", name))
 
 
-def test_bvh_equals_brute_force_teapot(repo):
+BUILDERS = [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH]
+
+
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_bvh_equals_brute_force_teapot(repo, builder):
     pos, nrm = load_teapot(repo)
-    cpu, gpu = mesh_pair(pos, nrm, True)
+    cpu, gpu = mesh_pair(pos, nrm, True, builder)
     o, d = adversarial_rays(pos, 24000, 3)
     check_mesh(cpu, gpu, o, d)
     assert gpu.stats()["bvh_tris_tested"] < 0.05 * o.shape[0] * pos.shape[0]  # the BVH actually prunes
 
 
-def test_bvh_equals_brute_force_triangle_soup():
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_bvh_equals_brute_force_triangle_soup(builder):
     rng = np.random.default_rng(5)
     n = 30000
     centre = (rng.random((n, 1, 3)) - 0.5) * 20
     pos = (centre + (rng.random((n, 3, 3)) - 0.5) * rng.choice([0.05, 0.5, 3.0], (n, 1, 1))).astype(np.float32)
     pos[:50] = pos[50:100]            # exact duplicates: ties must go to the lowest index
     pos[100:110, 2] = pos[100:110, 1]  # degenerate (zero-area) triangles never hit
-    cpu, gpu = mesh_pair(pos, None, False)
+    cpu, gpu = mesh_pair(pos, None, False, builder)
     o, d = adversarial_rays(pos, 6000, 8)
     check_mesh(cpu, gpu, o, d)
+
+
+def test_device_lbvh_degenerate_meshes_and_errors():
+    """The device builder on inputs that stress its tie-breaks: all triangles identical (every Morton key equal), a flat
+    grid (one axis without extent), sizes around the leaf size; and its error behaviour."""
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    grid = np.array([[[x, y, 0], [x + 1, y, 0], [x, y + 1, 0]] for y in range(20) for x in range(20)], np.float32)
+    cases = [np.repeat(tri[None], 37, 0), grid] + [grid[:n] for n in (5, 6, 9, 17)]
+    for pos in cases:
+        cpu, gpu = mesh_pair(pos, None, False, abi.BVH_DEVICE_LBVH)
+        rng = np.random.default_rng(len(pos))
+        hi = pos.reshape(-1, 3)[:, :2].max(0)
+        # from above: the triangles face +z, and only entering hits are visible (environment.rs:39-44)
+        o = np.concatenate([rng.uniform(-0.3, 1.0, (600, 2)) * (hi + 0.3), np.full((600, 1), 3.0)], axis=1).astype(np.float32)
+        d = np.tile(np.array([0, 0, -1], np.float32), (600, 1))
+        d[300:] += rng.normal(0, 0.2, (300, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        g, c = gpu.trace(o, d), cpu.trace(o, d)
+        assert (c["object_id"] != abi.MISS).sum() > 5
+        for k in ("object_id", "prim_id", "distance"):
+            assert np.array_equal(bits(g[k]), bits(c[k])), (len(pos), k)
+        assert gpu.stats()["ms_bvh_build"] > 0
+    with pytest.raises(rrt.RrtError) as e:
+        mesh_pair(grid, None, False, 7)
+    assert e.value.code == abi.ERR_INVALID
+
+
+def test_device_lbvh_frames_equal_host_sah_frames(repo):
+    """Whole frames (mesh + plane + light, shadows, FalseColour and Phong) are bit-identical whichever builder made the tree."""
+    frames = []
+    for builder in BUILDERS:
+        gpu, cam = rrt.Scene.load(os.path.join(repo, "assets/scenes/scene2.txt"), params=rrt.default_params(bvh_builder=builder),
+                                  mode_override=abi.MODE_SCENE)
+        gpu.pre_render(1)
+        cam.width, cam.height = 320, 240
+        frames.append(gpu.render(cam))
+    for a, b in zip(*frames):
+        assert np.array_equal(bits(a), bits(b))
 
 
 def test_bvh_tiny_meshes():

@@ -290,3 +290,16 @@ def test_api_argument_checks():
     with pytest.raises(rrt.RrtError) as e:
         s.object_transform(q, np.zeros((4, 4), np.float32))
     assert "not invertible" in e.value.message
+
+
+def test_device_lbvh_functions_pass_the_cpu_preflight(repo, tmp_path):
+    """tools/cpu_emu/lbvh_check.cpp runs the bodies of the device BVH build kernels (bvh_lbvh.h) serially under
+    AddressSanitizer and checks every tree exhaustively (structure, containment, depth)."""
+    import subprocess
+
+    exe = tmp_path / "lbvh_check"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++20", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-I" + os.path.join(repo, "tools/cpu_emu"), "-I" + os.path.join(repo, "rust-raytracer_amd/csrc"), "-o", str(exe),
+                           os.path.join(repo, "tools/cpu_emu/lbvh_check.cpp")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
