@@ -8,6 +8,13 @@ scene resident in HBM, outputs written to HBM.  Metric: Mrays/s = (primary + sec
 rays traced) / wall time.  With N ranks every rank renders its own frame of a camera orbit per step
 (frames are independent objects: no data-path collective), so scaling is "weak".
 
+Frames in flight.  The deep recursion levels of a frame hold few rays: their launches cost one wave's latency each and
+leave most of the GPU idle, and every frame ends with a host round trip for its counters.  Independent frames fill
+those gaps, so a rank drives `--frames-in-flight` (default 3: with torch's own stream that makes the 4 hardware queues a
+process has on this pool) frame pipelines -- a scene handle, a host thread and a HIP
+stream each, exactly what a host application rendering a camera path would do with this library -- and the K timed
+steps are dealt round-robin to them.  `config.value_one_frame_in_flight` is the same measurement with one pipeline.
+
 Extra legs (same JSON line):
   `cpu_baseline`  the CPU oracle (a port of the reference's brute-force algorithm; the Rust binary cannot be
                   built here: no Rust toolchain) rendering whole frames of the same workload for >= 12 s on
@@ -18,7 +25,9 @@ Extra legs (same JSON line):
                   applies is the vector FP32 rate ("valu_fp32", 157.3 TFLOP/s, which counts an FMA as two).
                   achieved = algorithmic flops (per-primitive flops of the reference's brute
                   force loop x rays traced, + 27 per ray/box and 61 per ray/triangle test) / HIP-event time of
-                  the launches on their stream (rrt_stats.ms_trace_kernels).  `traffic` = HBM bytes per launch
+                  the launches on their stream (rrt_stats.ms_trace_kernels), taken in a pass of its own that
+                  renders the same frames one at a time (overlapping launches share the GPU, so their durations
+                  would not add up to GPU time).  `traffic` = HBM bytes per launch
                   from the committed PMC passes (profiles/r01_final/pmc_traffic.json, FETCH_SIZE doubled as
                   the MI355X guide prescribes for 16-B-per-lane reads); `hbm_frac` prices the same launches
                   against 8 TB/s to show how far from the HBM roof the kernel is.
@@ -92,10 +101,13 @@ def measured_traffic(scene_path, width, height):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="independent frame pipelines per rank (scene handle + host thread + HIP stream each); the steps "
+                         "are dealt round-robin to them.  1 = every frame finishes before the next one starts")
     ap.add_argument("--streams", type=int, default=0, help="rrt_params.render_streams (0 = library default)")
     ap.add_argument("--static-camera", action="store_true", help="render the same frame every step")
     ap.add_argument("--scene", default=os.path.join(REPO, "assets/scenes/c2_quadric_csg_fresnel.txt"))
@@ -108,62 +120,130 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: librrt has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # RRT_BENCH_REHEARSAL=1: run the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, gloo instead
+    # of RCCL, which refuses two ranks on one device).  For checking the launch / sharding / reduction plumbing only.
+    rehearsal = os.environ.get("RRT_BENCH_REHEARSAL") == "1"
+    device_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+    reduce_device = "cpu" if rehearsal else "cuda"
 
     rrt = importlib.import_module("rust-raytracer_amd")
-    scene, cam0 = rrt.Scene.load(args.scene, params=rrt.default_params(render_streams=args.streams))
-    scene.pre_render(seed=1)
-    W, H = cam0.width, cam0.height
-    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-    depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
-    ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    F = max(1, args.frames_in_flight)
 
-    def step(i):
-        cam = cam0 if args.static_camera else orbit_camera(rrt, cam0, rank, i)
-        scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), stream)
-        return scene.stats()
+    class Worker:
+        """One frame pipeline: its own scene handle (the handle owns queues, counters and statistics; calls on one handle
+        are not re-entrant), output buffers and HIP stream, driven by its own host thread."""
+
+        def __init__(self, k):
+            self.k = k
+            self.scene, self.cam0 = rrt.Scene.load(args.scene, params=rrt.default_params(render_streams=args.streams))
+            self.scene.pre_render(seed=1)
+            W, H = self.cam0.width, self.cam0.height
+            self.rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+            self.depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
+            self.ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
+            self.stream = torch.cuda.Stream() if F > 1 else torch.cuda.current_stream()
+            self.reset()
+
+        def reset(self):
+            self.rays = self.flops = self.repeated = 0
+            self.kernel_ms = 0.0
+            self.frames = 0
+            self.error = None
+
+        def step(self, i):
+            cam = self.cam0 if args.static_camera else orbit_camera(rrt, self.cam0, rank, i)
+            self.scene.render_device(cam, 0, cam.height, self.rgb.data_ptr(), self.depth.data_ptr(), self.ids.data_ptr(), self.stream.cuda_stream)
+            st = self.scene.stats()
+            self.rays += st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+            self.kernel_ms += st["ms_trace_kernels"]
+            self.flops += st["flops_algorithmic"]
+            self.repeated = st["frames_repeated"]
+            self.frames += 1
+
+        def run(self, first, count, stride):  # frames first, first + stride, ... < count
+            try:
+                for i in range(first, count, stride):
+                    self.step(i)
+            except Exception as e:  # surfaces in the main thread
+                self.error = e
+
+    workers = [Worker(k) for k in range(F)]
+    cam0 = workers[0].cam0
+    W, H = cam0.width, cam0.height
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(n, active):
+        """n steps (frames 0 .. n-1), dealt round-robin to the `active` workers, each on its own thread."""
+        if len(active) == 1:
+            active[0].run(0, n, 1)
+        else:
+            import threading
+
+            th = [threading.Thread(target=w.run, args=(j, n, len(active))) for j, w in enumerate(active)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        for w in active:
+            if w.error is not None:
+                raise w.error
+
+    for w in workers:  # set-up, not warm-up: every pipeline sizes its queues once
+        w.step(0)
+    run_steps(args.warmup, workers)
+    for w in workers:
+        w.reset()
     sync()
-    rays = 0
-    kernel_ms = 0.0
-    flops = 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        st = step(i)
-        rays += st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
-        kernel_ms += st["ms_trace_kernels"]
-        flops += st["flops_algorithmic"]
+    run_steps(args.steps, workers)
     sync()
     dt = time.perf_counter() - t0
-
+    rays = sum(w.rays for w in workers)
+    repeated = sum(w.repeated for w in workers)
+    st_frames = sum(w.frames for w in workers)
+    assert st_frames == args.steps, (st_frames, args.steps)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        r = torch.tensor([rays], dtype=torch.float64, device="cuda")
+        r = torch.tensor([rays], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         total_rays = float(r.item())
     else:
         total_rays = float(rays)
 
+    # Roofline pass: the same frames ONE AT A TIME on pipeline 0.  Per-launch HIP-event durations only add up to GPU time
+    # when launches of different frames do not overlap; with several frames in flight each launch shares the GPU with
+    # the neighbours' launches and its duration says nothing about the kernel.
+    w0 = workers[0]
+    w0.reset()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    w0.run(0, min(args.steps, 40), 1)
+    torch.cuda.synchronize()
+    dt_one = time.perf_counter() - t1
+    if w0.error is not None:
+        raise w0.error
+    kernel_ms, flops, one_frames, one_rays = w0.kernel_ms, w0.flops, w0.frames, w0.rays
+
     if rank == 0:
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         traffic = measured_traffic(args.scene, W, H)
         launches = 6  # recursion levels 0..5 of a frame
-        hbm_gbs = traffic * launches / (kernel_ms / max(1, args.steps) * 1e-3) / 1e9 if traffic and kernel_ms > 0 else None
+        hbm_gbs = traffic * launches / (kernel_ms / max(1, one_frames) * 1e-3) / 1e9 if traffic and kernel_ms > 0 else None
         out = {
             "metric": "Mrays/s (primary+secondary+shadow rays traced)",
             "value": total_rays / dt / 1e6,
@@ -179,10 +259,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: quadric + CSG + Fresnel scene, 1920x1080, one frame per rank per step",
+                "frames_in_flight": F,
+                "value_one_frame_in_flight": one_rays / dt_one / 1e6,
                 "scene": os.path.relpath(args.scene, REPO),
                 "rays_per_frame": rays // max(1, args.steps),
-                "parallelism": "frames sharded over %d rank(s), no collective" % world,
-                "frames_repeated": st["frames_repeated"],
+                "parallelism": "frames sharded over %d rank(s), no collective" % world + (" (REHEARSAL: ranks share devices)" if rehearsal else ""),
+                "frames_repeated": repeated,
             },
             "roofline": {
                 "kernel": "k_trace_shade (all recursion levels of a frame)",
@@ -196,8 +278,9 @@ def main():
                 "hbm_gb_per_s": hbm_gbs,
                 "hbm_frac": hbm_gbs / PEAK_HBM_GBS if hbm_gbs else None,
                 "launches_per_frame": launches,
-                "kernel_ms_per_frame": kernel_ms / max(1, args.steps),
-                "algorithmic_flops_per_frame": flops // max(1, args.steps),
+                "kernel_ms_per_frame": kernel_ms / max(1, one_frames),
+                "algorithmic_flops_per_frame": flops // max(1, one_frames),
+                "pass": "%d of the same frames, one at a time on one pipeline, right after the timed region" % one_frames,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
