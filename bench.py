@@ -11,9 +11,10 @@ rays traced) / wall time.  With N ranks every rank renders its own frame of a ca
 Frames in flight.  The deep recursion levels of a frame hold few rays: their launches cost one wave's latency each and
 leave most of the GPU idle, and every frame ends with a host round trip for its counters.  Independent frames fill
 those gaps, so a rank drives `--frames-in-flight` (default 3: with torch's own stream that makes the 4 hardware queues a
-process has on this pool) frame pipelines -- a scene handle, a host thread and a HIP
-stream each, exactly what a host application rendering a camera path would do with this library -- and the K timed
-steps are dealt round-robin to them.  `config.value_one_frame_in_flight` is the same measurement with one pipeline.
+process has on this pool) frame pipelines -- a host thread and a HIP stream each, all rendering on ONE scene handle
+(concurrent render calls on a handle are part of the C ABI, as `raytrace(&self)` is in the reference), exactly what a
+host application rendering a camera path would do with this library -- and the K timed steps are dealt round-robin to
+them.  `config.value_one_frame_in_flight` is the same measurement with one pipeline.
 
 Extra legs (same JSON line):
   `cpu_baseline`  the CPU oracle (a port of the reference's brute-force algorithm; the Rust binary cannot be
@@ -138,14 +139,17 @@ def main():
     rrt = importlib.import_module("rust-raytracer_amd")
     F = max(1, args.frames_in_flight)
 
+    shared_scene, shared_cam = rrt.Scene.load(args.scene, params=rrt.default_params(render_streams=args.streams))
+    shared_scene.pre_render(seed=1)
+
     class Worker:
-        """One frame pipeline: its own scene handle (the handle owns queues, counters and statistics; calls on one handle
-        are not re-entrant), output buffers and HIP stream, driven by its own host thread."""
+        """One frame pipeline: a host thread with its own output buffers and HIP stream, rendering on the SHARED scene
+        handle (concurrent render calls on one handle each get their own queues inside the library; the flattened scene
+        is in HBM once).  rrt_get_stats returns the calling thread's own last frame."""
 
         def __init__(self, k):
             self.k = k
-            self.scene, self.cam0 = rrt.Scene.load(args.scene, params=rrt.default_params(render_streams=args.streams))
-            self.scene.pre_render(seed=1)
+            self.scene, self.cam0 = shared_scene, shared_cam
             W, H = self.cam0.width, self.cam0.height
             self.rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
             self.depth = torch.empty((H, W), dtype=torch.float32, device="cuda")

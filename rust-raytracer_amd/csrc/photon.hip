@@ -457,6 +457,7 @@ static int build_index(rrt_scene *s, int which) {
     X.count = n;
     X.inv_cell = 1.0f / (2.0f * s->params.gather_half_width);
     X.table_size = 0;
+    s->map_view[which] = X.view();
     if (n == 0) return RRT_OK;
     int rc;
     PhotonScratch &W = s->photon_scratch;
@@ -485,6 +486,7 @@ static int build_index(rrt_scene *s, int which) {
     hipLaunchKernelGGL(k_insert_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, X.keys.p, X.ranges.p, size - 1);
     RRT_HIP(hipGetLastError());
     RRT_HIP(hipDeviceSynchronize());
+    s->map_view[which] = X.view();
     return RRT_OK;
 }
 
@@ -517,7 +519,7 @@ int rrt_photon_begin(rrt_scene *s, uint64_t seed) {
     if (s->mode != RRT_MODE_PHOTON) return fail(RRT_ERR_STATE, "scene is not a PhotonScene");
     for (const rrt_light_desc &l : s->lights)
         if (l.kind == RRT_LIGHT_DIRECTIONAL) return fail(RRT_ERR_INVALID, "Light does not support photon mapping");  // light.rs:16-18
-    int rc = flatten_scene(s);
+    int rc = flatten_scene(s);  // drops the render workers
     if (rc) return rc;
     s->seed = seed;
     s->maps_built = false;
@@ -628,6 +630,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         RRT_HIP(hipEventElapsedTime(&ms, e0, e1));
         got[0] += s->local[0].count;
         got[1] += s->local[1].count;
+        s->epoch++;                      // statistics change outside a render call
         s->stats.ms_photon_shoot += ms;  // shooting kernel + compaction
         s->stats.photons_emitted += count;
         uint64_t caustic_before = s->local[1].count;
@@ -665,6 +668,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
 int rrt_photon_build(rrt_scene *s) {
     if (!s) return fail(RRT_ERR_INVALID, "null scene");
     if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_photon_begin has not been called");
+    drop_render_workers(s);  // the index arrays they read are rebuilt
     hipEvent_t e0 = s->events[0], e1 = s->events[1];
     RRT_HIP(hipEventRecord(e0, nullptr));
     int rc;

@@ -349,6 +349,7 @@ int flatten_materials(rrt_scene *s, std::vector<DevMaterial> &out, bool &reflect
 }  // namespace
 
 int flatten_scene(rrt_scene *s) {
+    drop_render_workers(s);  // they point into the device arrays replaced below
     Flat F;
     if (s->params.bvh_builder > RRT_BVH_DEVICE_LBVH) return fail(RRT_ERR_INVALID, "unknown bvh_builder");
     F.bvh_builder = s->params.bvh_builder;
@@ -586,8 +587,8 @@ void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, ui
     memset(&A, 0, sizeof(A));
     A.S = D.view;
     if (cam) A.cam = *cam;
-    A.maps[0] = s->index[0].view();
-    A.maps[1] = s->index[1].view();
+    A.maps[0] = s->map_view[0];
+    A.maps[1] = s->map_view[1];
     A.max_depth = depth_cap;
     A.mode = (uint32_t)s->mode;
     A.y0 = y0;
@@ -808,7 +809,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     }
     float ms_total = 0.0f;
     RRT_HIP(hipEventElapsedTime(&ms_total, s->events[0], s->events[1]));
-    rrt_stats &R = s->stats;
+    rrt_stats &R = s->render_stats;
     R.rays_primary = n_pixels;
     R.rays_secondary = secondary;
     R.rays_shadow = st[ST_SHADOW];
@@ -827,16 +828,105 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     return RRT_OK;
 }
 
+static int render_rays_on(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
+                          const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream) {
+    static const bool level_sync = getenv("RRT_LEVEL_SYNC") != nullptr;  // debugging aid: always size levels by readback
+    bool retry = false;
+    int rc = render_rays_impl(s, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream, !level_sync, retry);
+    if (rc == RRT_OK && retry) s->render_stats.frames_repeated++;
+    if (rc == RRT_OK && retry)
+        rc = render_rays_impl(s, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream, false, retry);
+    return rc;
+}
+
+void drop_render_workers(rrt_scene *s) {
+    std::lock_guard<std::mutex> lock(s->render_mutex);
+    s->workers.clear();
+    s->epoch++;
+}
+
+namespace {
+
+// statistics of the calling thread's last render call, per handle: concurrent callers each see their own frame
+struct ThreadStats {
+    const rrt_scene *scene = nullptr;
+    uint64_t epoch = 0;
+    rrt_stats stats{};
+};
+thread_local ThreadStats t_stats;
+
+std::unique_ptr<rrt_scene> make_worker(const rrt_scene *s) {
+    std::unique_ptr<rrt_scene> w(new rrt_scene());
+    w->is_worker = true;
+    w->mode = s->mode;
+    w->params = s->params;
+    w->flattened = true;
+    w->maps_built = s->maps_built;
+    w->seed = s->seed;
+    // the scene by pointer: w->dev owns no buffers
+    w->dev.view = s->dev.view;
+    w->dev.lds_slots = s->dev.lds_slots;
+    w->dev.bvh_stack = s->dev.bvh_stack;
+    w->dev.lds_bytes = s->dev.lds_bytes;
+    w->dev.reflective = s->dev.reflective;
+    w->dev.flops_per_trace = s->dev.flops_per_trace;
+    w->map_view[0] = s->map_view[0];
+    w->map_view[1] = s->map_view[1];
+    return w;
+}
+
+void copy_render_stats(rrt_stats &to, const rrt_stats &from) {
+    to.rays_primary = from.rays_primary;
+    to.rays_secondary = from.rays_secondary;
+    to.rays_shadow = from.rays_shadow;
+    to.bvh_nodes_visited = from.bvh_nodes_visited;
+    to.bvh_tris_tested = from.bvh_tris_tested;
+    to.photons_gathered = from.photons_gathered;
+    to.gather_queries = from.gather_queries;
+    to.gather_candidates = from.gather_candidates;
+    to.flops_per_trace = from.flops_per_trace;
+    to.flops_algorithmic = from.flops_algorithmic;
+    to.ms_trace_kernels = from.ms_trace_kernels;
+    to.ms_total = from.ms_total;
+}
+
+}  // namespace
+
 int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
                 const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream) {
     if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
     if (s->mode == RRT_MODE_PHOTON && !s->maps_built) return fail(RRT_ERR_STATE, "Photon map not built");
-    static const bool level_sync = getenv("RRT_LEVEL_SYNC") != nullptr;  // debugging aid: always size levels by readback
-    bool retry = false;
-    int rc = render_rays_impl(s, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream, !level_sync, retry);
-    if (rc == RRT_OK && retry) s->stats.frames_repeated++;
-    if (rc == RRT_OK && retry)
-        rc = render_rays_impl(s, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream, false, retry);
+    rrt_scene *w = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(s->render_mutex);
+        if (!s->busy) {
+            w = s;
+        } else {
+            for (auto &c : s->workers)
+                if (!c->busy) {
+                    w = c.get();
+                    break;
+                }
+            if (!w) {
+                if (s->workers.size() >= 64) return fail(RRT_ERR_LIMIT, "more than 65 concurrent render calls on one scene handle");
+                s->workers.push_back(make_worker(s));
+                w = s->workers.back().get();
+            }
+        }
+        w->busy = true;
+    }
+    int rc = w == s ? RRT_OK : ensure_workspace(w);
+    const uint64_t repeated_before = w->render_stats.frames_repeated;
+    if (rc == RRT_OK) rc = render_rays_on(w, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream);
+    {
+        std::lock_guard<std::mutex> lock(s->render_mutex);
+        copy_render_stats(s->stats, w->render_stats);
+        s->stats.frames_repeated += w->render_stats.frames_repeated - repeated_before;
+        t_stats.scene = s;
+        t_stats.epoch = s->epoch;
+        t_stats.stats = s->stats;
+        w->busy = false;
+    }
     return rc;
 }
 
@@ -868,6 +958,7 @@ DevCamera to_dev(const rrt_camera *c) {
 }
 
 void invalidate(rrt_scene *s) {
+    drop_render_workers(s);
     s->flattened = false;
     s->maps_built = false;
 }
@@ -1208,7 +1299,9 @@ int rrt_shadowtrace(rrt_scene *s, const float *origins, const float *directions,
 
 int rrt_get_stats(const rrt_scene *s, rrt_stats *out) {
     if (!s || !out) return fail(RRT_ERR_INVALID, "null argument");
-    *out = s->stats;
+    std::lock_guard<std::mutex> lock(const_cast<rrt_scene *>(s)->render_mutex);
+    // the calling thread's own last frame, if it rendered on this handle since the scene last changed
+    *out = (t_stats.scene == s && t_stats.epoch == s->epoch) ? t_stats.stats : s->stats;
     return RRT_OK;
 }
 

@@ -4,6 +4,7 @@
 
 #include <memory>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "host_scene.h"
@@ -144,8 +145,20 @@ struct rrt_scene {
     rrt::DBuf<uint32_t> counters;             // error word of the batch entry points
     rrt::DBuf<unsigned long long> stats_dev;  // StatSlot counters
     uint32_t *host_pinned = nullptr;          // readback staging
-    rrt_stats stats{};
+    rrt_stats stats{};         // what rrt_get_stats reports; written under render_mutex by render calls
+    rrt_stats render_stats{};  // the render fields of the call that currently holds this handle / worker
     std::vector<hipEvent_t> events;
+
+    // Concurrent render calls on one handle (the reference's Environment is Sync: raytrace(&self) runs on every render
+    // thread, scene.rs:83, camera.rs:22-40).  The handle's own queues / counters serve the first caller; callers that
+    // arrive while it is busy lease a WORKER: a light clone that shares the flattened scene and the photon maps by
+    // pointer and owns only queues, counters, events and statistics.  Anything that rebuilds device data drops them.
+    std::mutex render_mutex;
+    bool busy = false;                                 // the handle's own render state is in use
+    std::vector<std::unique_ptr<rrt_scene>> workers;   // their `busy` flags are guarded by render_mutex too
+    bool is_worker = false;
+    uint64_t epoch = 0;                                // bumped by whatever changes `stats` outside a render call
+    rrt::DevPhotonMap map_view[2]{};                   // what the render kernels read (index[].view(), shared with workers)
 
     // photon state
     rrt::PhotonBuffers local[2];  // this rank's records: regular, caustic
@@ -167,6 +180,7 @@ void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order,
 // bvh_lbvh.hip: the same outputs from the device-side LBVH build (n > 4); device_ms = HIP-event time of its kernels
 int build_bvh_device(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
                      float *device_ms);
+void drop_render_workers(rrt_scene *s);  // before device data of the scene or its photon maps is rebuilt
 int read_ppm(const std::string &path, HostTexture &tex);
 int load_obj(const std::string &path, bool smooth, std::vector<float> &tri_pos, std::vector<float> &tri_nrm);
 }  // namespace rrt

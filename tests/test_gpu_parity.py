@@ -6,6 +6,7 @@ photon-mapped frames within a stated MAE.  Where device libm (ocml) and glibc di
 ulp (atan2f/acosf feed sphere UVs, powf feeds the specular term) the affected quantities get the
 tolerance written next to the assert.
 """
+import ctypes as C
 import math
 import os
 
@@ -407,3 +408,70 @@ def test_render_rejects_bad_input(repo):
     cam.width = cam.height = 8
     rgb, depth, ids = empty.render(cam)  # a scene with no objects: scene.rs:85-90
     assert (ids == abi.MISS).all() and not rgb.any() and not depth.any()
+
+
+def test_concurrent_render_calls_on_one_handle(repo):
+    """Environment is Sync in the reference (raytrace(&self) runs on every render thread, camera.rs:22-40): several threads
+    may render on ONE scene handle at once.  Each call gets its own queues (a worker that shares the scene by pointer);
+    frames and per-thread statistics equal the sequential ones bit for bit, for row bands and for whole frames."""
+    import threading
+
+    gpu, cam = rrt.Scene.load(os.path.join(repo, "assets/scenes/c2_quadric_csg_fresnel.txt"))
+    gpu.pre_render(1)
+    cam.width, cam.height = 256, 144
+    cams = []
+    for k in range(6):
+        c = type(cam)()
+        C.memmove(C.byref(c), C.byref(cam), C.sizeof(cam))
+        c.position[0] = cam.position[0] + 0.05 * k
+        cams.append(c)
+    want, want_rays = [], []
+    for c in cams:
+        want.append(gpu.render(c))
+        st = gpu.stats()
+        want_rays.append((st["rays_primary"], st["rays_secondary"], st["rays_shadow"]))
+    assert len(set(want_rays)) > 1                      # the frames really differ
+    got, got_rays, errors = [None] * len(cams), [None] * len(cams), []
+
+    def work(tid, n_threads):
+        try:
+            for rep in range(3):
+                for k in range(tid, len(cams), n_threads):
+                    got[k] = gpu.render(cams[k])
+                    st = gpu.stats()                    # this thread's own last frame
+                    got_rays[k] = (st["rays_primary"], st["rays_secondary"], st["rays_shadow"])
+        except Exception as e:
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(t, 3)) for t in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for k in range(len(cams)):
+        for a, b in zip(want[k], got[k]):
+            assert np.array_equal(bits(a), bits(b)), k
+        assert got_rays[k] == want_rays[k], k
+    # bands of one frame from two threads at once (the reference's render_rows split)
+    half = cam.height // 2
+    parts = [None, None]
+
+    def band(j):
+        try:
+            parts[j] = gpu.render(cams[0], j * half, (j + 1) * half)
+        except Exception as e:
+            errors.append(e)
+
+    th = [threading.Thread(target=band, args=(j,)) for j in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for a, b0, b1 in zip(want[0], parts[0], parts[1]):
+        assert np.array_equal(bits(a), bits(np.concatenate([b0, b1])))
+    # a rebuild drops the workers; the handle keeps working
+    gpu.pre_render(1)
+    for a, b in zip(want[2], gpu.render(cams[2])):
+        assert np.array_equal(bits(a), bits(b))

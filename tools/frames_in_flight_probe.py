@@ -1,5 +1,5 @@
-"""Throughput of F independent frames in flight on one GPU: F scene handles, F host threads, F streams (ctypes releases
-the GIL during rrt_render_device).   usage: python tools/frames_in_flight_probe.py [scene] [frames]"""
+"""Throughput of F independent frames in flight on one GPU: F host threads and F streams on ONE scene handle, or with
+SEPARATE_HANDLES=1 on F handles (ctypes releases the GIL during rrt_render_device).   usage: python tools/frames_in_flight_probe.py [scene] [frames]"""
 import importlib, os, sys, threading, time
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,10 +11,15 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 
 
 class Worker:
+    shared = None
+
     def __init__(self, k):
         self.k = k
-        self.scene, self.cam0 = rrt.Scene.load(path)
-        self.scene.pre_render(seed=1)
+        if os.environ.get("SEPARATE_HANDLES") or Worker.shared is None:
+            scene, cam0 = rrt.Scene.load(path)
+            scene.pre_render(seed=1)
+            Worker.shared = (scene, cam0)
+        self.scene, self.cam0 = Worker.shared
         W, H = self.cam0.width, self.cam0.height
         self.rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
         self.depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
@@ -45,3 +50,4 @@ for F in (1, 2, 3, 4, 6):
     dt = time.perf_counter() - t0
     print("frames in flight %d: %.3f ms/frame, %.0f Mrays/s" % (F, dt / frames * 1e3, sum(w.rays for w in ws) / dt / 1e6), flush=True)
     del ws
+    Worker.shared = None
