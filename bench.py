@@ -175,6 +175,7 @@ def main():
 
         def run(self, first, count, stride):  # frames first, first + stride, ... < count
             try:
+                torch.cuda.set_device(device_index)  # HIP's current device is per thread; new threads start on device 0
                 for i in range(first, count, stride):
                     self.step(i)
             except Exception as e:  # surfaces in the main thread

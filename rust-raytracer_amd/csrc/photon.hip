@@ -534,6 +534,7 @@ int rrt_photon_begin(rrt_scene *s, uint64_t seed) {
 
 int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t count) {
     if (!s) return fail(RRT_ERR_INVALID, "null scene");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (!s->flattened || s->seeds.size() != s->lights.size()) return fail(RRT_ERR_STATE, "rrt_photon_begin has not been called");
     if (light < 0 || light >= (int)s->lights.size() || pass < 0 || pass > 1) return fail(RRT_ERR_INVALID, "bad light/pass");
     if (count == 0) return RRT_OK;
@@ -667,6 +668,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
 
 int rrt_photon_build(rrt_scene *s) {
     if (!s) return fail(RRT_ERR_INVALID, "null scene");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_photon_begin has not been called");
     drop_render_workers(s);  // the index arrays they read are rebuilt
     hipEvent_t e0 = s->events[0], e1 = s->events[1];
@@ -693,6 +695,7 @@ int rrt_photon_count(rrt_scene *s, int which, uint64_t *count) {
 
 int rrt_photon_read(rrt_scene *s, int which, float *position, float *incident, float *intensity, uint8_t *type, uint64_t *key) {
     if (!s || which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     PhotonBuffers &b = s->local[which];
     size_t n = b.count;
     if (n == 0) return RRT_OK;
@@ -728,6 +731,7 @@ int rrt_photon_caustic_count(rrt_scene *s, int light, uint64_t *count) {
 }
 int rrt_photon_caustic_export_device(rrt_scene *s, int light, float *pos4_dev, float *incident4_dev, uint64_t *key_dev) {
     if (!s || light < 0 || light >= (int)s->seeds.size() || !pos4_dev || !incident4_dev || !key_dev) return fail(RRT_ERR_INVALID, "bad argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     CausticSeeds &cs = *s->seeds[light];
     if (cs.count == 0) return RRT_OK;
     RRT_HIP(hipMemcpy(pos4_dev, cs.pos.p, cs.count * 16, hipMemcpyDeviceToDevice));
@@ -738,6 +742,7 @@ int rrt_photon_caustic_export_device(rrt_scene *s, int light, float *pos4_dev, f
 int rrt_photon_caustic_import_device(rrt_scene *s, int light, const float *pos4_dev, const float *incident4_dev, const uint64_t *key_dev,
                                      uint64_t count) {
     if (!s || light < 0 || light >= (int)s->seeds.size()) return fail(RRT_ERR_INVALID, "bad argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (count && (!pos4_dev || !incident4_dev || !key_dev)) return fail(RRT_ERR_INVALID, "null argument");
     if (count >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "too many caustic seeds");
     return rebuild_seeds(s, light, (const float4 *)pos4_dev, (const float4 *)incident4_dev, key_dev, count);
@@ -745,6 +750,7 @@ int rrt_photon_caustic_import_device(rrt_scene *s, int light, const float *pos4_
 int rrt_photon_local_count(rrt_scene *s, int which, uint64_t *count) { return rrt_photon_count(s, which, count); }
 int rrt_photon_export_device(rrt_scene *s, int which, float *pos4_dev, float *incident4_dev, float *intensity4_dev, uint64_t *meta_dev) {
     if (!s || which < 0 || which > 1 || !pos4_dev || !incident4_dev || !intensity4_dev || !meta_dev) return fail(RRT_ERR_INVALID, "bad argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     PhotonBuffers &b = s->local[which];
     if (b.count == 0) return RRT_OK;
     RRT_HIP(hipMemcpy(pos4_dev, b.pos.p, b.count * 16, hipMemcpyDeviceToDevice));
@@ -756,6 +762,7 @@ int rrt_photon_export_device(rrt_scene *s, int which, float *pos4_dev, float *in
 int rrt_photon_import_device(rrt_scene *s, int which, const float *pos4_dev, const float *incident4_dev, const float *intensity4_dev,
                              const uint64_t *meta_dev, uint64_t count) {
     if (!s || which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (count && (!pos4_dev || !incident4_dev || !intensity4_dev || !meta_dev)) return fail(RRT_ERR_INVALID, "null argument");
     if (count >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
     PhotonBuffers &b = s->local[which];
@@ -776,6 +783,7 @@ int rrt_photon_import_device(rrt_scene *s, int which, const float *pos4_dev, con
 int rrt_photon_query(rrt_scene *s, int which, const float *positions, size_t n, float half_width, uint32_t k_max, uint32_t *count, uint64_t *key,
                      float *dist2) {
     if (!s || which < 0 || which > 1 || !positions || !count) return fail(RRT_ERR_INVALID, "bad argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (k_max && (!key || !dist2)) return fail(RRT_ERR_INVALID, "null output array");
     if (!s->maps_built) return fail(RRT_ERR_STATE, "Photon map not built");
     if (!(half_width >= 0.0f)) return fail(RRT_ERR_INVALID, "bad half width");
@@ -817,6 +825,7 @@ const size_t kPmapChunk = 1u << 22;  // records per host staging chunk (64 MiB o
 
 int rrt_photon_save(rrt_scene *s, const char *path) {
     if (!s || !path) return fail(RRT_ERR_INVALID, "null argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (s->mode != RRT_MODE_PHOTON) return fail(RRT_ERR_STATE, "scene is not a PhotonScene");
     int rc;
     for (int w = 0; w < 2; w++)
@@ -853,6 +862,7 @@ int rrt_photon_save(rrt_scene *s, const char *path) {
 
 int rrt_photon_load(rrt_scene *s, const char *path) {
     if (!s || !path) return fail(RRT_ERR_INVALID, "null argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (s->mode != RRT_MODE_PHOTON) return fail(RRT_ERR_STATE, "scene is not a PhotonScene");
     if (!s->flattened || s->seeds.size() != s->lights.size()) return fail(RRT_ERR_STATE, "rrt_photon_begin has not been called");
     FILE *f = fopen(path, "rb");

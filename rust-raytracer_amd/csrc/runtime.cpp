@@ -421,6 +421,7 @@ int flatten_scene(rrt_scene *s) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(RRT_ERR_DEVICE, "no HIP device: librrt has no CPU fallback");
+    RRT_HIP(hipGetDevice(&s->device));  // the caller's current device owns this scene from here on
     // the hit lists keep the record index of each hit in 16 bits (mk_meta in dev_trace.h)
     if (has_csg && F.prog.size() > 0xFFFF) return fail(RRT_ERR_LIMIT, "scene with CSG objects has more than 65535 primitive records");
     DeviceScene &D = s->dev;
@@ -839,6 +840,14 @@ static int render_rays_on(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint3
     return rc;
 }
 
+int use_scene_device(const rrt_scene *s) {
+    if (s->device < 0) return RRT_OK;
+    int cur = -1;
+    RRT_HIP(hipGetDevice(&cur));
+    if (cur != s->device) RRT_HIP(hipSetDevice(s->device));
+    return RRT_OK;
+}
+
 void drop_render_workers(rrt_scene *s) {
     std::lock_guard<std::mutex> lock(s->render_mutex);
     s->workers.clear();
@@ -863,6 +872,7 @@ std::unique_ptr<rrt_scene> make_worker(const rrt_scene *s) {
     w->flattened = true;
     w->maps_built = s->maps_built;
     w->seed = s->seed;
+    w->device = s->device;
     // the scene by pointer: w->dev owns no buffers
     w->dev.view = s->dev.view;
     w->dev.lds_slots = s->dev.lds_slots;
@@ -896,6 +906,10 @@ int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixe
                 const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream) {
     if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
     if (s->mode == RRT_MODE_PHOTON && !s->maps_built) return fail(RRT_ERR_STATE, "Photon map not built");
+    {
+        int rc_dev = use_scene_device(s);  // render threads other than the one that built the scene start on device 0
+        if (rc_dev) return rc_dev;
+    }
     rrt_scene *w = nullptr;
     {
         std::lock_guard<std::mutex> lock(s->render_mutex);
@@ -1188,6 +1202,7 @@ int rrt_render_device(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t
 
 int rrt_render(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t y1, float *rgb, float *depth, uint32_t *object_id) {
     if (!s || !cam) return fail(RRT_ERR_INVALID, "null argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (y0 > y1 || y1 > cam->height) return fail(RRT_ERR_INVALID, "bad row range");
     if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
     size_t n = (size_t)(y1 - y0) * cam->width;
@@ -1207,6 +1222,7 @@ int rrt_render(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t y1, fl
 
 int rrt_raytrace(rrt_scene *s, const float *origins, const float *directions, size_t n, float *rgb, float *depth, uint32_t *object_id) {
     if (!s || !origins || !directions) return fail(RRT_ERR_INVALID, "null argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
     if (n >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 rays");
     DBuf<float> d_o, d_d, d_rgb, d_depth;
@@ -1227,6 +1243,7 @@ int rrt_raytrace(rrt_scene *s, const float *origins, const float *directions, si
 static int batch_common(rrt_scene *s, const float *origins, const float *directions, const float *limits, size_t n, uint32_t *object_id,
                         uint32_t *prim_id, float *distance, float *position, float *normal, float *uv, uint8_t *occluded, bool shadow) {
     if (!s || !origins || !directions) return fail(RRT_ERR_INVALID, "null argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_pre_render has not been called");
     if (n >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 rays");
     DBuf<float> d_o, d_d, d_lim, d_dist, d_pos, d_nrm, d_uv;

@@ -139,6 +139,7 @@ struct rrt_scene {
 
     bool flattened = false;
     bool maps_built = false;
+    int device = -1;  // the HIP device rrt_pre_render ran on: every later call on the handle makes it current for its thread
     uint64_t seed = 0;
     rrt::DeviceScene dev;
     std::vector<std::unique_ptr<rrt::RenderLane>> lanes;  // see render_rays (DBuf is not movable: lanes stay put)
@@ -180,7 +181,9 @@ void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order,
 // bvh_lbvh.hip: the same outputs from the device-side LBVH build (n > 4); device_ms = HIP-event time of its kernels
 int build_bvh_device(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
                      float *device_ms);
-void drop_render_workers(rrt_scene *s);  // before device data of the scene or its photon maps is rebuilt
+void drop_render_workers(rrt_scene *s);
+// HIP's current device is per thread (new threads start on device 0): entry points that touch the scene's memory call this
+int use_scene_device(const rrt_scene *s);  // before device data of the scene or its photon maps is rebuilt
 int read_ppm(const std::string &path, HostTexture &tex);
 int load_obj(const std::string &path, bool smooth, std::vector<float> &tri_pos, std::vector<float> &tri_nrm);
 }  // namespace rrt
