@@ -114,11 +114,14 @@ def run_mesh(rrt, torch, steps=5, bvh_builder=0):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     achieved = flops / (kernel_ms * 1e-3) / 1e12
+    ms_3 = frames_in_flight_ms(torch, scene, cam, 9)
     return {
         "workload": "BASELINE configs[3]: %d-triangle mesh (13x13 teapot.obj grid) + floor, 3840x2160, 1 point light" % ntri,
         "value": rays / dt / 1e6,
         "unit": "Mrays/s",
         "ms_per_frame": dt / steps * 1e3,
+        "ms_per_frame_3_frames_in_flight": ms_3,
+        "value_3_frames_in_flight": (rays / steps) / (ms_3 * 1e-3) / 1e6,
         "rays_per_frame": rays // steps,
         "hit_fraction": float((ids >= 0).float().mean().item()),
         "bvh_nodes_per_ray": st["bvh_nodes_visited"] / (st["rays_primary"] + st["rays_shadow"]),
@@ -129,6 +132,44 @@ def run_mesh(rrt, torch, steps=5, bvh_builder=0):
         "roofline": {"kernel": "k_trace_shade", "bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "kernel_ms_per_frame": kernel_ms / steps},
     }
+
+
+def frames_in_flight_ms(torch, scene, cam, frames, in_flight=3):
+    """ms per frame with `in_flight` render calls on ONE scene handle at a time (a host thread and a HIP stream each; the
+    library gives concurrent calls their own queues).  The same frame every time: throughput of the render pass."""
+    import threading
+
+    W, H = cam.width, cam.height
+    dev = torch.cuda.current_device()
+    bufs = [(torch.empty((H, W, 3), dtype=torch.float32, device="cuda"), torch.empty((H, W), dtype=torch.float32, device="cuda"),
+             torch.empty((H, W), dtype=torch.int32, device="cuda"), torch.cuda.Stream()) for _ in range(in_flight)]
+    errors = []
+
+    def work(j, n):
+        try:
+            torch.cuda.set_device(dev)
+            rgb, depth, ids, st = bufs[j]
+            for _ in range(n):
+                scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), st.cuda_stream)
+        except Exception as e:
+            errors.append(e)
+
+    def go(n):
+        th = [threading.Thread(target=work, args=(j, n)) for j in range(in_flight)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    go(1)  # every pipeline sizes its queues once
+    torch.cuda.synchronize()
+    per = max(1, frames // in_flight)
+    t0 = time.perf_counter()
+    go(per)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (per * in_flight) * 1e3
 
 
 def run_photon(rrt, torch, photons=1_000_000, steps=3):
@@ -162,6 +203,7 @@ def run_photon(rrt, torch, photons=1_000_000, steps=3):
         cand += st["gather_candidates"]
         queries += st["gather_queries"]
         stored = st["photons_stored_regular"] + st["photons_stored_caustic"]
+    ms_3 = frames_in_flight_ms(torch, scene, cam, 9)
     emitted = (photons + 10_000) * steps
     # algorithmic bytes of the gather: 36 B per photon inside a query cube + 8 B per touched cell
     gather_bytes = 36.0 * gathered + 8.0 * 8 * queries
@@ -170,8 +212,9 @@ def run_photon(rrt, torch, photons=1_000_000, steps=3):
         "workload": "BASELINE configs[2]: scene2 photon mode, %d + 10000 photons, seed 1.., 1024x1024" % photons,
         "mphotons_per_s_emitted_trace_pass": emitted / t_shoot / 1e6,
         "mphotons_per_s_gathered_render_pass": gathered / t_render / 1e6,
+        "mphotons_per_s_gathered_render_pass_3_frames_in_flight": (gathered / steps) / (ms_3 * 1e-3) / 1e6,
         "ms": {"photon_shoot": t_shoot / steps * 1e3, "index_build": t_build / steps * 1e3, "render": t_render / steps * 1e3,
-               "render_kernels": kernel_ms / steps},
+               "render_kernels": kernel_ms / steps, "render_3_frames_in_flight": ms_3},
         "records_stored": stored,
         "gathered_per_frame": gathered // steps,
         "candidates_read_per_frame": cand // steps,

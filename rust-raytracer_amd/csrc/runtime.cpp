@@ -639,7 +639,9 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     unsigned long long *st_all = reinterpret_cast<unsigned long long *>(s->host_pinned);  // RRT_STAT_WORDS slots
     bool tail_done = false;
 
-    for (uint32_t round_base = 0; round_base < n_pixels;) {
+    uint32_t round = 0;
+    static const std::vector<uint32_t> no_prediction;
+    for (uint32_t round_base = 0; round_base < n_pixels; round++) {
         // the chunks of this round, one per lane
         std::vector<ChunkPlan> plan;
         for (uint32_t j = 0; j < want_lanes && round_base < n_pixels; j++) {
@@ -653,7 +655,8 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
         }
         bool predicted = allow_predicted && n_levels > 1;
         for (size_t j = 0; j < plan.size(); j++) {
-            const std::vector<uint32_t> &pred = s->lanes[j]->prediction;
+            const auto &all = s->lanes[j]->prediction;
+            const std::vector<uint32_t> &pred = round < all.size() ? all[round] : no_prediction;
             if (!(pred.size() == n_levels + 2 && pred[0] == plan[j].n)) predicted = false;
         }
         if (predicted) {
@@ -664,7 +667,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
             for (size_t j = 0; j < plan.size(); j++) {
                 RenderLane &L = *s->lanes[j];
                 hipStream_t st = j == 0 ? stream : L.stream;
-                const std::vector<uint32_t> &pred = L.prediction;
+                const std::vector<uint32_t> &pred = L.prediction[round];
                 std::vector<uint32_t> caps(n_levels + 1, 0);
                 caps[0] = plan[j].n;
                 if ((rc = L.levels[0].ensure(plan[j].n, n_lights, cam == nullptr))) return rc;
@@ -792,7 +795,8 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
         }
         if (n_levels > 1)  // what the next frame's chunks of these sizes will be launched for
             for (size_t j = 0; j < plan.size(); j++) {
-                std::vector<uint32_t> &pred = s->lanes[j]->prediction;
+                if (s->lanes[j]->prediction.size() <= round) s->lanes[j]->prediction.resize(round + 1);
+                std::vector<uint32_t> &pred = s->lanes[j]->prediction[round];
                 pred.assign(n_levels + 2, 0);
                 pred[0] = plan[j].n;
                 for (uint32_t k = 0; k <= n_levels; k++) pred[1 + k] = plan[j].counts[k];

@@ -123,7 +123,9 @@ struct RenderLane {
     bool owns_pinned = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev_trace0 = nullptr, ev_trace1 = nullptr, ev_done = nullptr;
-    std::vector<uint32_t> prediction;  // [0] = chunk size it was measured on, [1 + k] = size of level k
+    // per round of chunks of a frame (a frame larger than the chunk size takes several rounds, each over another part of
+    // the image): [0] = chunk size it was measured on, [1 + k] = size of level k
+    std::vector<std::vector<uint32_t>> prediction;
 };
 }  // namespace rrt
 

@@ -111,6 +111,24 @@ def test_predicted_level_sizes_and_their_fallback(repo):
     assert np.array_equal(first[2], id_c) and np.array_equal(bits(first[1]), bits(depth_c))
 
 
+def test_frames_of_several_chunk_rounds_keep_their_predictions(repo):
+    """A frame larger than the chunk size goes through several rounds of chunks, each over another part of the image with
+    its own level sizes: every round keeps its own prediction, so steady-state frames are not repeated."""
+    _, gpu, cam = load_pair(repo, "c2_quadric_csg_fresnel", params=rrt.default_params(chunk_pixels=8192))
+    cam.width, cam.height = 256, 160    # 5 rounds of 8192 pixels
+    gpu.pre_render(1)
+    first = gpu.render(cam)
+    for _ in range(3):
+        again = gpu.render(cam)
+        for a, b in zip(first, again):
+            assert np.array_equal(bits(a), bits(b))
+    assert gpu.stats()["frames_repeated"] == 0
+    whole, _ = rrt.Scene.load(os.path.join(repo, "assets/scenes/c2_quadric_csg_fresnel.txt"), mode_override=abi.MODE_SCENE)
+    whole.pre_render(1)
+    for a, b in zip(first, whole.render(cam)):
+        assert np.array_equal(bits(a), bits(b))
+
+
 def test_chunks_on_several_streams_match_single_stream_and_oracle(repo):
     """With rrt_params.render_streams > 1, frames of 2^18 pixels and more are cut into one chunk per stream so that deep
     recursion levels of one chunk may overlap shallow levels of another: same bits as on one stream, same as the oracle."""
