@@ -1,11 +1,14 @@
-"""Photon-mapped scene2 (1 M photons, 1024^2), ONE frame at a time: rrt_params.render_streams = 1, 2, 4, 8 and chunk sizes."""
+"""Photon-mapped scene2 (1024^2): rrt_params.render_streams = 1, 2, 4, 8 -- one frame at a time and three frames in flight.
+   usage: python tools/photon_streams_probe.py [photons]"""
 import importlib, os, sys, time
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+import bench_extra
 rrt = importlib.import_module("rust-raytracer_amd")
-for streams, chunk in ((1, 0), (2, 0), (4, 0), (8, 0), (1, 1 << 18), (1, 1 << 16)):
-    params = rrt.default_params(photons_per_light=1_000_000, caustic_photons_per_light=10_000, render_streams=streams, chunk_pixels=chunk)
+photons = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+for streams in (1, 2, 3, 4, 6, 8):
+    params = rrt.default_params(photons_per_light=photons, caustic_photons_per_light=10_000, render_streams=streams)
     scene, cam = rrt.Scene.load(os.path.join(REPO, "assets/scenes/scene2.txt"), params=params)
     scene.pre_render(1)
     W, H = cam.width, cam.height
@@ -13,6 +16,8 @@ for streams, chunk in ((1, 0), (2, 0), (4, 0), (8, 0), (1, 1 << 18), (1, 1 << 16
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(2): scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), st)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(5): scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), st)
+    for _ in range(6): scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), st)
     torch.cuda.synchronize()
-    print("render_streams %d chunk %d: %.2f ms/frame (kernels %.2f, repeated %d)" % (streams, chunk, (time.perf_counter() - t0) / 5 * 1e3, scene.stats()["ms_trace_kernels"], scene.stats()["frames_repeated"]), flush=True)
+    one = (time.perf_counter() - t0) / 6 * 1e3
+    three = bench_extra.frames_in_flight_ms(torch, scene, cam, 12)
+    print("render_streams %d: %.2f ms/frame alone, %.2f ms/frame with 3 in flight (repeated %d)" % (streams, one, three, scene.stats()["frames_repeated"]), flush=True)
