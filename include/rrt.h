@@ -61,7 +61,11 @@ typedef struct rrt_params {
                                            RRT_BVH_DEVICE_LBVH (1): Morton-order build on the GPU for meshes of more
                                            than 4 triangles (rebuilds in milliseconds; same frames, slower traversal).
                                            The reference has no acceleration structure (polymesh_object.rs:219-236) */
-    uint32_t reserved[7];
+    uint32_t gather_heavy_threshold;    /* photon mode: a radiance estimate whose two query boxes hold more candidate
+                                           records than this is gathered by a whole wave in a second kernel instead of by
+                                           its lane (0 = default 2048; 0xFFFFFFFF = never).  Same photons; the f32 sums
+                                           are added in another (fixed) order                                           */
+    uint32_t reserved[6];
 } rrt_params;
 enum rrt_bvh_builder { RRT_BVH_HOST_SAH = 0, RRT_BVH_DEVICE_LBVH = 1 };
 

@@ -25,7 +25,8 @@ class Params(C.Structure):
         ("chunk_pixels", C.c_uint32),
         ("render_streams", C.c_uint32),
         ("bvh_builder", C.c_uint32),
-        ("reserved", C.c_uint32 * 7),
+        ("gather_heavy_threshold", C.c_uint32),
+        ("reserved", C.c_uint32 * 6),
     ]
 
 

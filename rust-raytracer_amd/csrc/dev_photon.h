@@ -154,14 +154,39 @@ __device__ __forceinline__ void gather_box(const DevPhotonMap &G, f3 p, float r,
     }
 }
 
-// average_photon_at (photon_scene.rs:363-420): regular and caustic estimates and their blend
-__device__ __forceinline__ bool average_photon_at(const DevPhotonMap maps[2], f3 p, float r, f3 &incident, f3 &intensity,
-                                                  unsigned long long &gathered, unsigned long long &candidates) {
-    GatherSums reg, cau;
-    gather_box(maps[0], p, r, reg);
-    gather_box(maps[1], p, r, cau);
-    gathered += reg.k + cau.k;
-    candidates += reg.candidates + cau.candidates;
+// the 2 x 2 x 2 cells a query box overlaps (cell edge = box edge), looked up; false when rounding made it 3 along an axis
+struct CellSet {
+    uint2 rg[8];
+    uint32_t candidates;
+};
+__device__ __forceinline__ bool lookup_cells(const DevPhotonMap &G, f3 lo, f3 hi, CellSet &C) {
+    C.candidates = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) C.rg[c] = make_uint2(0, 0);
+    if (G.count == 0) return true;
+    uint32_t x0 = cell_coord(lo.x, G.inv_cell), x1 = cell_coord(hi.x, G.inv_cell);
+    uint32_t y0 = cell_coord(lo.y, G.inv_cell), y1 = cell_coord(hi.y, G.inv_cell);
+    uint32_t z0 = cell_coord(lo.z, G.inv_cell), z1 = cell_coord(hi.z, G.inv_cell);
+    if (!(x1 - x0 <= 1u && y1 - y0 <= 1u && z1 - z0 <= 1u)) return false;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        uint32_t cx = x0 + (c >> 2), cy = y0 + ((c >> 1) & 1u), cz = z0 + (c & 1u);
+        if (cx <= x1 && cy <= y1 && cz <= z1) C.rg[c] = lookup_cell(G, cell_key(cx, cy, cz));
+        C.candidates += C.rg[c].y;
+    }
+    return true;
+}
+__device__ __forceinline__ void stream_cells(const DevPhotonMap &G, const CellSet &C, f3 lo, f3 hi, GatherSums &s) {
+    s.ldir = mk3(0.0f, 0.0f, 0.0f);
+    s.intensity = mk3(0.0f, 0.0f, 0.0f);
+    s.k = 0;
+    s.candidates = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) stream_cell(G, C.rg[c], lo, hi, s);
+}
+
+// the blend of average_photon_at (photon_scene.rs:363-420) from the two maps' sums
+__device__ __forceinline__ bool blend_estimates(const GatherSums &reg, const GatherSums &cau, f3 &incident, f3 &intensity) {
     float nr = (float)reg.k, nc = (float)cau.k;
     f3 r_dir = norm3(reg.ldir), r_int = reg.intensity / nr;
     f3 c_dir = norm3(cau.ldir), c_int = cau.intensity / nc;
@@ -179,6 +204,62 @@ __device__ __forceinline__ bool average_photon_at(const DevPhotonMap maps[2], f3
     incident = r_dir;
     intensity = r_int + c_int * (nc / (nc + nr));
     return true;
+}
+
+// average_photon_at (photon_scene.rs:363-420): regular and caustic estimates and their blend.
+// Returns 0: no photons, 1: estimate in (incident, intensity), 2: DEFERRED -- the two boxes hold more than `defer_above`
+// candidate records, nothing was read, the caller files the query for k_gather_heavy (pass 0xFFFFFFFF to never defer).
+__device__ __forceinline__ int average_photon_at(const DevPhotonMap maps[2], f3 p, float r, uint32_t defer_above, f3 &incident, f3 &intensity,
+                                                 unsigned long long &gathered, unsigned long long &candidates) {
+    GatherSums reg, cau;
+    f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);  // photon_tree.rs:16-18
+    CellSet c0, c1;
+    if (lookup_cells(maps[0], lo, hi, c0) && lookup_cells(maps[1], lo, hi, c1)) {
+        if (c0.candidates + c1.candidates > defer_above) return 2;
+        stream_cells(maps[0], c0, lo, hi, reg);
+        stream_cells(maps[1], c1, lo, hi, cau);
+    } else {  // a box that touches 3 cells along an axis (rounding): the general walk
+        gather_box(maps[0], p, r, reg);
+        gather_box(maps[1], p, r, cau);
+    }
+    gathered += reg.k + cau.k;
+    candidates += reg.candidates + cau.candidates;
+    return blend_estimates(reg, cau, incident, intensity) ? 1 : 0;
+}
+
+// One query, a whole wave (all 64 lanes active, wave-uniform control flow): the cells' records are strided over the
+// lanes and the partial sums are combined by a fixed butterfly, so the result depends only on the query and the map
+// (not on which lane or wave ran it).  Same photon set as gather_box; the f32 sums differ by rounding only.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void wave_gather_box(const DevPhotonMap &G, f3 p, float r, GatherSums &s) {
+    f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);
+    CellSet C;
+    if (!lookup_cells(G, lo, hi, C)) {  // rounding made the box touch 3 cells along an axis: every lane does the general walk
+        gather_box(G, p, r, s);
+        return;
+    }
+    GatherSums part;
+    part.ldir = mk3(0.0f, 0.0f, 0.0f);
+    part.intensity = mk3(0.0f, 0.0f, 0.0f);
+    part.k = 0;
+    part.candidates = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t first = min(C.rg[c].x, G.count), n = min(C.rg[c].y, G.count - first);  // guard: stay inside the map
+        for (uint32_t k = lane; k < n; k += 64u) take_record(G, first + k, G.pos_cell[first + k], lo, hi, part);
+    }
+    s.ldir = mk3(wave_sum_f32(part.ldir.x), wave_sum_f32(part.ldir.y), wave_sum_f32(part.ldir.z));
+    s.intensity = mk3(wave_sum_f32(part.intensity.x), wave_sum_f32(part.intensity.y), wave_sum_f32(part.intensity.z));
+    uint32_t k = part.k;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) k += (uint32_t)__shfl_xor((int)k, off, 64);
+    s.k = k;
+    s.candidates = C.candidates;
 }
 
 }  // namespace rrt

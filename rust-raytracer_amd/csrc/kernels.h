@@ -36,6 +36,17 @@ enum StatSlot { ST_NODES = 0, ST_TRIS, ST_SHADOW, ST_GATHERED, ST_QUERIES, ST_CA
 #define RRT_STAT_STRIDE 8  // slots per copy (ST_COUNT rounded up to a 64-byte line)
 #define RRT_STAT_WORDS (RRT_STAT_COPIES * RRT_STAT_STRIDE)
 
+// A photon-mode hit whose two radiance-estimate queries would read more than `heavy_threshold` candidate records is
+// not gathered by its lane: the lane files this record and k_gather_heavy gives the query a whole wave.
+struct HeavyRec {
+    float4 pos_u;    // hit position, u
+    float4 nrm_v;    // hit normal, v
+    float4 dir_mat;  // ray direction, material index as uint bits
+    uint32_t node, has_tex, pad0, pad1;
+};
+#define RRT_HEAVY_THRESHOLD 2048u       // default for rrt_params.gather_heavy_threshold
+#define RRT_HEAVY_COUNTER 32            // lane counters [32 + level] count the records filed by that level
+
 struct TraceArgs {
     DevScene S;
     LevelBuffers cur, next;
@@ -55,6 +66,10 @@ struct TraceArgs {
     uint32_t *next_count;
     uint32_t *err;
     unsigned long long *stats;
+    HeavyRec *heavy;           // null: every lane gathers for itself
+    uint32_t heavy_capacity;   // records the queue holds (the chunk size: every query of a level may be heavy)
+    uint32_t *heavy_count;     // this level's counter
+    uint32_t heavy_threshold;  // candidate records (both maps) above which a query is filed
     // level-0 outputs of the combine pass (any may be null)
     float *out_rgb;
     float *out_depth;
@@ -63,6 +78,7 @@ struct TraceArgs {
 
 void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream);
 void launch_combine(const TraceArgs &a, hipStream_t stream);
+void launch_gather_heavy(const TraceArgs &a, hipStream_t stream);  // after launch_trace_shade of the same level (photon mode)
 
 struct BatchTraceArgs {
     DevScene S;

@@ -98,9 +98,12 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
     unsigned long long gathered = 0, queries = 0, candidates = 0;
     bool want_a = false, want_b = false;  // a: reflection child, b: refraction child
     f3 ao = mk3(0, 0, 0), ad = mk3(0, 0, 0), bo = mk3(0, 0, 0), bd = mk3(0, 0, 0);
+    bool defer = false;  // photon mode: this lane's radiance estimate goes to k_gather_heavy
+    HitAttr h;
+    f3 o, d;
+    h.material = 0;
 
     if (active) {
-        f3 o, d;
         if (A.level == 0 && A.cam.width != 0) {
             uint32_t pixel = node_pixel(A.pixel_base + i, A.cam.width, A.band_rows);
             camera_ray(A.cam, pixel % A.cam.width, A.y0 + pixel / A.cam.width, o, d);
@@ -111,7 +114,6 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
         }
         TraceResult tr;
         trace<FEAT>(S, o, d, lds, cnt, tr);
-        HitAttr h;
         if (tr.object != 0xFFFFFFFFu) {
             eval_hit<FEAT>(S, o, d, tr.instr, tr.sub, tr.t, h);
             if ((uint32_t)h.material >= S.n_materials) {  // index guard of eval_hit tripped
@@ -171,8 +173,10 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
                 if (sw > 0.0f) {
                     f3 inc, inten;
                     queries += 2;
-                    if (average_photon_at(A.maps, h.position, A.gather_half_width, inc, inten, gathered, candidates))
-                        surface = material_render_vueon(S, M, h, inc, inten, -d, cnt);
+                    const int got = average_photon_at(A.maps, h.position, A.gather_half_width, A.heavy ? A.heavy_threshold : 0xFFFFFFFFu, inc,
+                                                      inten, gathered, candidates);
+                    if (got == 1) surface = material_render_vueon(S, M, h, inc, inten, -d, cnt);
+                    defer = got == 2;  // `once` is written by k_gather_heavy (or below, if the queue is full)
                 }
                 bool deeper = A.level + 1 <= A.max_depth;
                 if (rw > 0.0f && deeper) {
@@ -191,6 +195,36 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
                 }
                 A.cur.once[i] = make_float4(surface.x, surface.y, surface.z, 0.0f);
                 A.cur.glob[i] = make_float4(rw, sw, 0.0f, __uint_as_float(flags));
+            }
+        }
+    }
+
+    // ---- photon mode: file the heavy radiance estimates (one atomic per wave; few waves have any) ----
+    if (MODE == RRT_MODE_PHOTON) {
+        const unsigned long long md = __ballot(defer);
+        if (md) {
+            const uint32_t ln = threadIdx.x & 63u;
+            uint32_t base = 0;
+            if (ln == (uint32_t)__ffsll((long long)md) - 1u) base = atomicAdd(A.heavy_count, (uint32_t)__popcll(md));
+            base = __shfl(base, __ffsll((long long)md) - 1, 64);
+            const uint32_t slot = base + (uint32_t)__popcll(md & (ln == 0 ? 0ULL : (~0ULL >> (64 - ln))));
+            if (defer) {
+                if (slot < A.heavy_capacity) {
+                    HeavyRec R;
+                    R.pos_u = make_float4(h.position.x, h.position.y, h.position.z, h.u);
+                    R.nrm_v = make_float4(h.normal.x, h.normal.y, h.normal.z, h.v);
+                    R.dir_mat = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)h.material));
+                    R.node = i;
+                    R.has_tex = h.has_tex ? 1u : 0u;
+                    R.pad0 = R.pad1 = 0u;
+                    A.heavy[slot] = R;
+                } else {  // queue full: this lane gathers for itself after all
+                    f3 inc, inten;
+                    f3 surface = mk3(0.0f, 0.0f, 0.0f);
+                    if (average_photon_at(A.maps, h.position, A.gather_half_width, 0xFFFFFFFFu, inc, inten, gathered, candidates) == 1)
+                        surface = material_render_vueon(S, S.materials[h.material], h, inc, inten, -d, cnt);
+                    A.cur.once[i] = make_float4(surface.x, surface.y, surface.z, 0.0f);
+                }
             }
         }
     }
@@ -267,6 +301,45 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
         }
     }
     if (active) A.cur.child[i] = child;
+}
+
+// Photon mode: the radiance estimates the trace kernel filed (HeavyRec), one query per wave.  Grid-stride over the
+// records: every wave leaves the loop once the records run out, nothing waits on anything.
+__global__ __launch_bounds__(64) void k_gather_heavy(TraceArgs A) {
+    const DevScene &S = A.S;
+    const uint32_t n = min(*A.heavy_count, A.heavy_capacity);
+    Counters cnt = {0, 0, 0, 0};
+    unsigned long long gathered = 0, candidates = 0;
+    for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
+        const HeavyRec R = A.heavy[q];
+        HitAttr h;
+        h.position = mk3(R.pos_u.x, R.pos_u.y, R.pos_u.z);
+        h.normal = mk3(R.nrm_v.x, R.nrm_v.y, R.nrm_v.z);
+        h.u = R.pos_u.w;
+        h.v = R.nrm_v.w;
+        h.has_tex = R.has_tex != 0u;
+        h.material = (int32_t)__float_as_uint(R.dir_mat.w);
+        const f3 d = mk3(R.dir_mat.x, R.dir_mat.y, R.dir_mat.z);
+        if ((uint32_t)h.material >= S.n_materials || R.node >= A.cur.capacity) {  // index guards
+            cnt.overflow |= RRT_ERR_BIT_INTERNAL;
+            continue;
+        }
+        GatherSums reg, cau;
+        wave_gather_box(A.maps[0], h.position, A.gather_half_width, reg);
+        wave_gather_box(A.maps[1], h.position, A.gather_half_width, cau);
+        gathered += reg.k + cau.k;
+        candidates += reg.candidates + cau.candidates;
+        f3 inc, inten;
+        f3 surface = mk3(0.0f, 0.0f, 0.0f);
+        if (blend_estimates(reg, cau, inc, inten)) surface = material_render_vueon(S, S.materials[h.material], h, inc, inten, -d, cnt);
+        if ((threadIdx.x & 63u) == 0) A.cur.once[R.node] = make_float4(surface.x, surface.y, surface.z, 0.0f);
+    }
+    if ((threadIdx.x & 63u) == 0) {  // every lane holds the same totals
+        unsigned long long *stats = A.stats + (blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE;
+        if (gathered) atomicAdd(&stats[ST_GATHERED], gathered);
+        if (candidates) atomicAdd(&stats[ST_CANDIDATES], candidates);
+        if (cnt.overflow) atomicOr(A.err, cnt.overflow);
+    }
 }
 
 __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
@@ -440,6 +513,11 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
     }
 #undef RRT_LAUNCH
 }
+void launch_gather_heavy(const TraceArgs &a, hipStream_t stream) {
+    if (!a.heavy || a.mode != RRT_MODE_PHOTON) return;
+    hipLaunchKernelGGL(k_gather_heavy, dim3(4096), dim3(64), 0, stream, a);
+}
+
 void launch_combine(const TraceArgs &a, hipStream_t stream) {
     if (a.count == 0) return;
     hipLaunchKernelGGL(k_combine, dim3(blocks_for(a.count)), dim3(RRT_BLOCK), 0, stream, a);

@@ -333,6 +333,15 @@ __global__ void k_insert_cells(const uint64_t *keys, uint32_t n, uint64_t *table
         slot = (slot + 1) & mask;
     }
 }
+// sum of count^2 over the occupied cells of the table, into 64 line-separated partial sums
+__global__ void k_cell_crowding(const uint64_t *table_keys, const uint2 *ranges, uint32_t size, unsigned long long *acc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (i < size && table_keys[i] != ~0ULL) v = (unsigned long long)ranges[i].y * ranges[i].y;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&acc[(blockIdx.x & 63u) * 8u], v);
+}
 __global__ void k_strip_key(const uint64_t *meta, uint32_t n, uint64_t *key) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) key[i] = meta[i] & 0x00FFFFFFFFFFFFFFull;
@@ -457,6 +466,7 @@ static int build_index(rrt_scene *s, int which) {
     X.count = n;
     X.inv_cell = 1.0f / (2.0f * s->params.gather_half_width);
     X.table_size = 0;
+    X.crowding = 0.0;
     s->map_view[which] = X.view();
     if (n == 0) return RRT_OK;
     int rc;
@@ -477,6 +487,7 @@ static int build_index(rrt_scene *s, int which) {
     hipLaunchKernelGGL(k_count_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, ncell.p);
     uint32_t cells = 0;
     RRT_HIP(hipMemcpy(&cells, ncell.p, 4, hipMemcpyDeviceToHost));
+    if (getenv("RRT_INDEX_INFO")) fprintf(stderr, "[index %d] %u records in %u cells (%.1f per occupied cell)\n", which, n, cells, (double)n / cells);
     if (cells >= (1u << 30)) return fail(RRT_ERR_LIMIT, "photon index above 2^30 occupied cells");
     uint32_t size = 64;
     while (size < 2 * cells) size <<= 1;
@@ -485,6 +496,18 @@ static int build_index(rrt_scene *s, int which) {
     hipLaunchKernelGGL(k_fill_u64, grid_for(size), dim3(256), 0, nullptr, X.keys.p, size, ~0ULL);
     hipLaunchKernelGGL(k_insert_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, X.keys.p, X.ranges.p, size - 1);
     RRT_HIP(hipGetLastError());
+    {   // how crowded the cells are where the photons are (sizes the default heavy-query threshold, runtime.cpp)
+        DBuf<uint64_t> &acc = W.keys;  // the unsorted cell keys are no longer needed
+        if ((rc = acc.ensure(512))) return rc;
+        RRT_HIP(hipMemsetAsync(acc.p, 0, 512 * sizeof(unsigned long long), nullptr));
+        hipLaunchKernelGGL(k_cell_crowding, grid_for(size), dim3(256), 0, nullptr, X.keys.p, X.ranges.p, size, (unsigned long long *)acc.p);
+        unsigned long long part[512];
+        RRT_HIP(hipMemcpy(part, acc.p, sizeof(part), hipMemcpyDeviceToHost));
+        unsigned long long sum = 0;
+        for (int k = 0; k < 64; k++) sum += part[k * 8];
+        X.crowding = (double)sum / (double)n;
+        if (getenv("RRT_INDEX_INFO")) fprintf(stderr, "[index %d] crowding %.1f\n", which, X.crowding);
+    }
     RRT_HIP(hipDeviceSynchronize());
     s->map_view[which] = X.view();
     return RRT_OK;
@@ -683,6 +706,13 @@ int rrt_photon_build(rrt_scene *s) {
     s->stats.ms_photon_build = ms;
     s->stats.photons_stored_regular = s->local[0].count;
     s->stats.photons_stored_caustic = s->local[1].count;
+    // Default heavy-query threshold: a query pair on a lit surface reads about 9 x crowding(regular map) candidate records
+    // (measured on scene2 from 1 M to 100 M photons); queries 4 x heavier than that are the tail of a launch and get a
+    // wave of their own.  A property of the maps, not of the camera: the same frame always takes the same path.
+    {
+        double t = 36.0 * s->index[0].crowding;
+        s->heavy_auto = t > 4.0e9 ? 0xFFFFFFFEu : std::max<uint32_t>(RRT_HEAVY_THRESHOLD, (uint32_t)t);
+    }
     s->maps_built = true;
     return RRT_OK;
 }

@@ -599,6 +599,9 @@ void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, ui
     A.gather_half_width = s->params.gather_half_width;
     A.err = L.ctr + 63;
     A.stats = s->stats_dev.p;
+    A.heavy = L.heavy.p;  // null unless render_rays_impl decided to use the queue
+    A.heavy_capacity = (uint32_t)std::min<size_t>(L.heavy.cap, 0xFFFFFFFFu);
+    A.heavy_threshold = s->params.gather_heavy_threshold ? s->params.gather_heavy_threshold : s->heavy_auto;
     A.out_rgb = rgb_dev;
     A.out_depth = depth_dev;
     A.out_id = id_dev;
@@ -629,6 +632,16 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     if ((rc = ensure_lanes(s, want_lanes))) return rc;
     for (uint32_t j = 0; j < want_lanes; j++)
         if (s->lanes[j]->levels.size() < n_levels + 1) s->lanes[j]->levels.resize(n_levels + 1);
+    // photon mode: heavy radiance estimates are filed per level (lane counters [32 + level]) and gathered by whole waves
+    const bool heavy_queue = s->mode == RRT_MODE_PHOTON && s->params.gather_heavy_threshold != 0xFFFFFFFFu && n_levels <= 30;
+    for (uint32_t j = 0; j < want_lanes; j++) {
+        if (heavy_queue) {  // sized for the chunk's pixels (deeper levels are smaller in practice); lanes that find the
+            // queue full gather for themselves
+            if ((rc = s->lanes[j]->heavy.ensure(std::min(chunk, n_pixels)))) return rc;
+        } else {
+            s->lanes[j]->heavy.release();
+        }
+    }
 
     RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, (RRT_STAT_WORDS + 32) * sizeof(unsigned long long), stream));  // + lane 0's counters
     bool lane0_clean = true;
@@ -692,7 +705,9 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     A.next_limit = caps[k + 1];
                     A.level = k;
                     A.next_count = L.ctr + (k + 1);
+                    A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
                     launch_trace_shade(A, D.lds_bytes, st);
+                    launch_gather_heavy(A, st);
                 }
                 RRT_HIP(hipEventRecord(L.ev_trace1, st));
                 for (int k = (int)n_levels - 1; k >= 0; k--) {
@@ -761,8 +776,10 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     A.next_limit = spawns ? 2 * counts[k] : 0;
                     A.level = k;
                     A.next_count = L.ctr + (k + 1);
+                    A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
                     RRT_HIP(hipEventRecord(L.ev_trace0, stream));
                     launch_trace_shade(A, D.lds_bytes, stream);
+                    launch_gather_heavy(A, stream);
                     RRT_HIP(hipEventRecord(L.ev_trace1, stream));
                     last = k;
                     uint32_t next_n = 0;
@@ -886,6 +903,7 @@ std::unique_ptr<rrt_scene> make_worker(const rrt_scene *s) {
     w->dev.flops_per_trace = s->dev.flops_per_trace;
     w->map_view[0] = s->map_view[0];
     w->map_view[1] = s->map_view[1];
+    w->heavy_auto = s->heavy_auto;
     return w;
 }
 

@@ -92,6 +92,7 @@ struct PhotonIndex {
     uint32_t table_size = 0;
     uint64_t count = 0;
     float inv_cell = 0.0f;
+    double crowding = 0.0;  // sum over cells of count^2 / records: the occupancy of the cell a random photon lies in
     DevPhotonMap view() const;
 };
 // Work arrays of the sorts and the index build, kept between calls (grow-only): hipMalloc / hipFree cost more than the
@@ -123,6 +124,7 @@ struct RenderLane {
     bool owns_pinned = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev_trace0 = nullptr, ev_trace1 = nullptr, ev_done = nullptr;
+    DBuf<HeavyRec> heavy;  // photon mode: the queries of the current level filed for k_gather_heavy
     // per round of chunks of a frame (a frame larger than the chunk size takes several rounds, each over another part of
     // the image): [0] = chunk size it was measured on, [1 + k] = size of level k
     std::vector<std::vector<uint32_t>> prediction;
@@ -161,6 +163,7 @@ struct rrt_scene {
     std::vector<std::unique_ptr<rrt_scene>> workers;   // their `busy` flags are guarded by render_mutex too
     bool is_worker = false;
     uint64_t epoch = 0;                                // bumped by whatever changes `stats` outside a render call
+    uint32_t heavy_auto = RRT_HEAVY_THRESHOLD;         // gather_heavy_threshold = 0 resolves to this (set by rrt_photon_build)
     rrt::DevPhotonMap map_view[2]{};                   // what the render kernels read (index[].view(), shared with workers)
 
     // photon state

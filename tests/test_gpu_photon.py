@@ -20,8 +20,8 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def pair(repo, name, photons, caustic):
-    params = rrt.default_params(photons_per_light=photons, caustic_photons_per_light=caustic)
+def pair(repo, name, photons, caustic, **more):
+    params = rrt.default_params(photons_per_light=photons, caustic_photons_per_light=caustic, **more)
     path = os.path.join(repo, "assets/scenes", name + ".txt")
     cpu, cam = ob.OracleScene.load(path, params=params, mode_override=abi.MODE_PHOTON)
     gpu, _ = rrt.Scene.load(path, params=params, mode_override=abi.MODE_PHOTON)
@@ -58,6 +58,39 @@ def test_photon_maps_and_frames_match_oracle(repo, name, photons, caustic):
     if name != "pm_diffuse":
         assert sg["photons_gathered"] == sc["photons_gathered"] and sg["gather_queries"] == sc["gather_queries"]
         assert sg["rays_secondary"] == sc["rays_secondary"]
+
+
+def test_heavy_radiance_estimates_gathered_by_whole_waves(repo):
+    """Queries over more than rrt_params.gather_heavy_threshold candidate records are filed by their lane and gathered by
+    a whole wave (k_gather_heavy).  Same photons, another fixed order of the f32 sums: counts exact, frames within the
+    same rounding as against the oracle, deterministic, and independent of how the frame is cut into bands."""
+    OFF = 0xFFFFFFFF
+    cpu, low, cam = pair(repo, "pm_caustics", 60000, 4000, gather_heavy_threshold=8)     # nearly every query is "heavy"
+    _, mid, _ = pair(repo, "pm_caustics", 60000, 4000, gather_heavy_threshold=300)      # a mix
+    _, off, _ = pair(repo, "pm_caustics", 60000, 4000, gather_heavy_threshold=OFF)
+    for s in (cpu, low, mid, off):
+        s.pre_render(21)
+    cam.width, cam.height = 200, 152
+    f_off = off.render(cam)
+    st_off = off.stats()
+    rgb_c, depth_c, id_c = cpu.render(cam)
+    for scene in (low, mid):
+        f = scene.render(cam)
+        st = scene.stats()
+        assert np.array_equal(f[2], f_off[2]) and np.array_equal(bits(f[1]), bits(f_off[1]))
+        for k in ("photons_gathered", "gather_queries", "gather_candidates", "rays_secondary"):
+            assert st[k] == st_off[k], k
+        assert st["photons_gathered"] == cpu.stats()["photons_gathered"] > 100000
+        d_off = np.abs(rrt.quantise(f[0]).astype(int) - rrt.quantise(f_off[0]).astype(int))
+        assert d_off.max() <= 1 and d_off.mean() < 0.02, (d_off.max(), d_off.mean())
+        dq = np.abs(ob.quantise(rgb_c).astype(int) - rrt.quantise(f[0]).astype(int))
+        assert dq.mean() < 0.05 and (dq > 1).mean() < 1e-3, (dq.mean(), dq.max())
+        again = scene.render(cam)
+        assert np.array_equal(bits(f[0]), bits(again[0]))                      # deterministic
+        half = 72                                                              # bands: other waves, other lanes, same sums
+        top, bottom = scene.render(cam, 0, half), scene.render(cam, half, cam.height)
+        assert np.array_equal(bits(f[0]), bits(np.concatenate([top[0], bottom[0]])))
+    assert not np.array_equal(bits(low.render(cam)[0]), bits(f_off[0]))        # the other order really was used
 
 
 def test_photon_pass_is_deterministic_and_split_independent(repo):
