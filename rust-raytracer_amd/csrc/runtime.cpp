@@ -683,13 +683,22 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                 const std::vector<uint32_t> &pred = L.prediction[round];
                 std::vector<uint32_t> caps(n_levels + 1, 0);
                 caps[0] = plan[j].n;
+                // Levels the previous frame left empty are not launched at all (a photon-mapped frame of scene2 has rays on 2
+                // of its 13 levels): the last launched level gets next_limit 0, so a ray that does want to go deeper raises
+                // RRT_ERR_BIT_QUEUE and the frame is repeated level by level, like any other outgrown prediction.
+                uint32_t n_run = n_levels;
+                for (uint32_t k = 1; k < n_levels; k++)
+                    if (pred[1 + k] == 0) {
+                        n_run = k;
+                        break;
+                    }
                 if ((rc = L.levels[0].ensure(plan[j].n, n_lights, cam == nullptr))) return rc;
-                for (uint32_t k = 1; k < n_levels; k++) {
+                for (uint32_t k = 1; k < n_run; k++) {
                     uint64_t want = (uint64_t)pred[1 + k] + pred[1 + k] / 8 + 4096;
                     caps[k] = (uint32_t)std::min<uint64_t>(want, 2ull * caps[k - 1]);
                     if ((rc = L.levels[k].ensure(caps[k], n_lights, true))) return rc;
                 }
-                if ((rc = L.levels[n_levels].ensure(1, n_lights, true))) return rc;
+                if ((rc = L.levels[n_run].ensure(1, n_lights, true))) return rc;
                 if (!(j == 0 && lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), st));
                 if (j == 0) lane0_clean = false;
                 if (!cam)
@@ -697,12 +706,12 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                 TraceArgs A;
                 fill_args(s, A, cam, y0, n_pixels, plan[j].base, depth_cap, L, rgb_dev, depth_dev, id_dev);
                 RRT_HIP(hipEventRecord(L.ev_trace0, st));
-                for (uint32_t k = 0; k < n_levels; k++) {
+                for (uint32_t k = 0; k < n_run; k++) {
                     A.cur = L.levels[k].view();
                     A.next = L.levels[k + 1].view();
                     A.count = caps[k];
                     A.count_ptr = k ? L.ctr + k : nullptr;
-                    A.next_limit = caps[k + 1];
+                    A.next_limit = caps[k + 1];  // 0 behind the last launched level
                     A.level = k;
                     A.next_count = L.ctr + (k + 1);
                     A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
@@ -710,7 +719,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     launch_gather_heavy(A, st);
                 }
                 RRT_HIP(hipEventRecord(L.ev_trace1, st));
-                for (int k = (int)n_levels - 1; k >= 0; k--) {
+                for (int k = (int)n_run - 1; k >= 0; k--) {
                     A.cur = L.levels[k].view();
                     A.next = L.levels[k + 1].view();
                     A.count = caps[k];
