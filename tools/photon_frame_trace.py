@@ -4,7 +4,8 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 rrt = importlib.import_module("rust-raytracer_amd")
-params = rrt.default_params(photons_per_light=int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, caustic_photons_per_light=10_000)
+params = rrt.default_params(photons_per_light=int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, caustic_photons_per_light=10_000,
+                            gather_heavy_threshold=int(os.environ.get("THR", "0")))
 scene, cam = rrt.Scene.load(os.path.join(REPO, "assets/scenes/scene2.txt"), params=params)
 scene.pre_render(1)
 W, H = cam.width, cam.height
