@@ -46,13 +46,26 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_boxes(const float *positions, u
             if (c == c) lo[k] = hi[k] = lbvh::ordered(c);  // a NaN centroid takes no part in the bounds
         }
     }
-    // all lanes of the block get here: whole-wave butterflies are safe
+    // all lanes of the block get here: whole-wave butterflies are safe.  One atomic per block and word (atomics of many
+    // waves on one address serialise in the L2)
+    __shared__ uint32_t s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
     for (int k = 0; k < 3; k++) {
         const uint32_t l = wave_min_u32(lo[k]), h = wave_max_u32(hi[k]);
         if ((threadIdx.x & 63) == 0) {
-            atomicMin(&bounds[k], l);
-            atomicMax(&bounds[3 + k], h);
+            s_lo[threadIdx.x >> 6][k] = l;
+            s_hi[threadIdx.x >> 6][k] = h;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        uint32_t l = s_lo[0][k], h = s_hi[0][k];
+        for (int w = 1; w < kBlock / 64; w++) {
+            l = min(l, s_lo[w][k]);
+            h = max(h, s_hi[w][k]);
+        }
+        atomicMin(&bounds[k], l);
+        atomicMax(&bounds[3 + k], h);
     }
 }
 // 2. keys
