@@ -190,24 +190,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The pipelines' host threads live for the whole run and wait at a barrier between phases: starting threads inside
+    # the timed region would cost about a frame's time each.
+    import threading
+
+    phase = {"n": 0, "stop": False}
+    gate_in, gate_out = threading.Barrier(F + 1), threading.Barrier(F + 1)
+
+    def pipeline_thread(j):
+        torch.cuda.set_device(device_index)
+        while True:
+            gate_in.wait()
+            if phase["stop"]:
+                return
+            workers[j].run(j, phase["n"], F)
+            gate_out.wait()
+
+    threads = [threading.Thread(target=pipeline_thread, args=(j,), daemon=True) for j in range(F)] if F > 1 else []
+    for t in threads:
+        t.start()
+
     def run_steps(n, active):
-        """n steps (frames 0 .. n-1), dealt round-robin to the `active` workers, each on its own thread."""
+        """n steps (frames 0 .. n-1), dealt round-robin to the pipelines (all of them, or pipeline 0 alone)."""
         if len(active) == 1:
             active[0].run(0, n, 1)
         else:
-            import threading
-
-            th = [threading.Thread(target=w.run, args=(j, n, len(active))) for j, w in enumerate(active)]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
+            phase["n"] = n
+            gate_in.wait()
+            gate_out.wait()
         for w in active:
             if w.error is not None:
                 raise w.error
 
-    for w in workers:  # set-up, not warm-up: every pipeline sizes its queues once
-        w.step(0)
+    # set-up, not warm-up: every pipeline renders one frame on its OWN thread (queue sizes, and whatever HIP sets up the
+    # first time a thread launches)
+    run_steps(F, workers)
     run_steps(args.warmup, workers)
     for w in workers:
         w.reset()
@@ -243,6 +260,11 @@ def main():
     if w0.error is not None:
         raise w0.error
     kernel_ms, flops, one_frames, one_rays = w0.kernel_ms, w0.flops, w0.frames, w0.rays
+    if threads:
+        phase["stop"] = True
+        gate_in.wait()
+        for t in threads:
+            t.join()
 
     if rank == 0:
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
