@@ -22,3 +22,59 @@ def test_c5_per_rank_share_100m_photons_4k(repo):
     assert rep["records_regular"] >= photons
     assert rep["gather_queries"] >= 3840 * 2160          # every pixel's first hit queries both maps, plus the vueons' hits
     assert rep["query_map0"]["largest_count"] > 1000      # the queries really were where the photons are
+
+
+def test_c4_million_triangle_mesh_4k_both_builders_and_oracle_sample(repo):
+    """BASELINE configs[3] at full size: 1 068 080 triangles at 3840x2160.  The reference's O(N) loop per ray is out of reach
+    for whole frames, so: (1) the frames of the host-SAH tree and of the device-LBVH tree are identical bit for bit (ids,
+    depth, rgb); (2) a sample of the 4K frame's camera rays goes through the oracle's brute force over all the triangles:
+    object, triangle, distance, position and normal bit-exact; (3) the frame is band-independent."""
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    import bench_extra
+    import oracle_binding as ob
+    import scene_kit as kit
+
+    rrt = ob.rrt
+    abi = rrt._abi
+    pos, nrm = bench_extra.teapot_grid()
+    cam = rrt.make_camera(3840, 2160, 0.6981317, (0.0, 260.0, -420.0), (0.0, 0.55, 1.0))
+
+    def build(scene):
+        scene.add_object(kit.mesh(scene, pos, nrm, kit.monochrome(scene, (0.8, 0.6, 0.2), 0.1, 50.0), True))
+        scene.add_object(kit.plane(scene, (0, 0, 0), (0, 0, 1), (0, 1, 0), kit.monochrome(scene, (0.3, 0.5, 0.3), 0.1, 100.0)))
+        kit.light(scene, abi.LIGHT_POINT, position=(0.0, 400.0, -300.0), colour=(1.2, 1.2, 1.2))
+        return scene
+
+    frames = []
+    scenes = []
+    for builder in (abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH):
+        s = build(rrt.Scene(params=rrt.default_params(bvh_builder=builder)))
+        s.pre_render(1)
+        frames.append(s.render(cam))
+        scenes.append(s)
+    bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    for a, b in zip(*frames):
+        assert np.array_equal(bits(a), bits(b))
+    rgb, depth, ids = frames[0]
+    assert (ids == 0).mean() > 0.1 and (ids == 1).mean() > 0.05          # teapots and floor both in view
+    top, bottom = scenes[1].render(cam, 0, 1000), scenes[1].render(cam, 1000, 2160)
+    assert np.array_equal(bits(np.concatenate([top[0], bottom[0]])), bits(rgb))
+    # oracle sample: camera rays of random pixels, brute force over every triangle
+    rng = np.random.default_rng(4)
+    px = np.stack([rng.integers(0, 3840, 96), rng.integers(0, 2160, 96)], axis=1)
+    rays = [rrt.camera_ray(cam, int(x), int(y)) for x, y in px]
+    o = np.array([r[0] for r in rays], np.float32)
+    d = np.array([r[1] for r in rays], np.float32)
+    cpu = build(ob.OracleScene())
+    c = cpu.trace(o, d)
+    for s in scenes:
+        g = s.trace(o, d)
+        for k in ("object_id", "prim_id", "distance", "position", "normal"):
+            assert np.array_equal(bits(g[k]), bits(c[k])), k
+    assert np.array_equal(c["object_id"], ids[px[:, 1], px[:, 0]])       # and they are the frame's primary hits
+    assert np.array_equal(bits(c["distance"]), bits(depth[px[:, 1], px[:, 0]]))
