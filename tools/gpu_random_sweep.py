@@ -1,7 +1,9 @@
 """A wider sweep of tests/test_gpu_random_scenes.py than the suite runs: seeds [first, first + count) through both test
 functions, failures listed, nothing stops at the first one.  (The photon test also asserts that a scene keeps more than
 300 regular records, a sanity check of the generator, not of parity: seeds 152 and 232 keep 256 and 259 and are otherwise
-record-for-record identical.)  Round 1: seeds 100-249 clean.   usage (GPU box): python tools/gpu_random_sweep.py [first [count]]"""
+record-for-record identical; so are the other 14 seeds below 1250 that trip it.)  Round 1: seeds 100-1249 clean: 1150
+scenes traced and rendered, 288 photon passes, every record and frame as the oracle's; seed 488's frame overflows a HitVec
+on both sides (now in the test suite).   usage (GPU box): python tools/gpu_random_sweep.py [first [count]]"""
 import os, sys, traceback
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
