@@ -342,10 +342,17 @@ int rrt_photon_import_device(rrt_scene *s, int which, const float *pos_dev, cons
  * the n query points the photons of map `which` (0 regular, 1 caustic) inside the closed cube of half width
  * `half_width` around it, ascending by squared distance (ties by key: the reference's sort is unstable there).
  * count[n] = photons inside the cube; key / dist2 [n][k_max] = the first min(count, k_max) of them (k_max = 0:
- * counts only; a k_max above count leaves the rest of the row untouched).  Host pointers.  `find_nearest`
- * (photon_tree.rs:37-39, unbounded k-NN, never called in the reference) has no counterpart yet.               */
+ * counts only; a k_max above count leaves the rest of the row untouched).  Host pointers.                       */
 int rrt_photon_query(rrt_scene *s, int which, const float *positions, size_t n, float half_width, uint32_t k_max,
                      uint32_t *count, uint64_t *key, float *dist2);
+/* PhotonTree::find_nearest (core/photon_tree.rs:37-39; kd-tree 0.5.1 `nearests`, never called by the reference), batched:
+ * for each of the n query points the k photons of map `which` closest to it in Euclidean distance, ascending by squared
+ * distance (ties by key).  count[n] = min(k, photons in the map); key / dist2 [n][k].  The hash grid is searched in cubes
+ * of doubling half width until the k-th distance fits inside the cube; points whose k nearest photons are farther than
+ * 64 index cells away are searched exhaustively on the host (maps of up to 2^26 records; RRT_ERR_LIMIT above).  Host
+ * pointers.                                                                                                          */
+int rrt_photon_nearest(rrt_scene *s, int which, const float *positions, size_t n, uint32_t k, uint32_t *count, uint64_t *key,
+                       float *dist2);
 
 /* Photon-map files: both maps of this rank (after rrt_photon_build's canonical sort order), so that cameras can be
  * re-rendered without re-shooting.  No counterpart in the reference (its maps live and die with the process);

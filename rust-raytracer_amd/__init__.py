@@ -102,6 +102,7 @@ _sig("rrt_photon_caustic_import_device", C.c_int, C.c_void_p, C.c_int, C.c_void_
 _sig("rrt_photon_local_count", C.c_int, C.c_void_p, C.c_int, _u64p)
 _sig("rrt_photon_export_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("rrt_photon_query", C.c_int, C.c_void_p, C.c_int, _f32p, C.c_size_t, C.c_float, C.c_uint32, _u32p, C.c_void_p, _f32p)
+_sig("rrt_photon_nearest", C.c_int, C.c_void_p, C.c_int, _f32p, C.c_size_t, C.c_uint32, _u32p, C.c_void_p, _f32p)
 _sig("rrt_photon_save", C.c_int, C.c_void_p, C.c_char_p)
 _sig("rrt_photon_load", C.c_int, C.c_void_p, C.c_char_p)
 _sig("rrt_photon_import_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -356,6 +357,16 @@ class Scene:
         check(lib.rrt_photon_query(self._h, which, _fp(p), n, C.c_float(half_width), k_max, count.ctypes.data_as(_u32p),
                                    key.ctypes.data_as(C.c_void_p), _fp(d2)))
         return count, key[:, :k_max], d2[:, :k_max]
+
+    def photon_nearest(self, which, positions, k):
+        """PhotonTree::find_nearest, batched: (count[n], key[n][k], dist2[n][k])."""
+        p = _f32(positions, (-1, 3))
+        n = p.shape[0]
+        count = np.zeros(n, np.uint32)
+        key = np.zeros((n, k), np.uint64)
+        d2 = np.full((n, k), np.inf, np.float32)
+        check(lib.rrt_photon_nearest(self._h, which, _fp(p), n, k, count.ctypes.data_as(_u32p), key.ctypes.data_as(C.c_void_p), _fp(d2)))
+        return count, key, d2
 
     def photon_save(self, path):
         check(lib.rrt_photon_save(self._h, str(path).encode()))

@@ -855,6 +855,77 @@ int rrt_photon_query(rrt_scene *s, int which, const float *positions, size_t n, 
     return RRT_OK;
 }
 
+// PhotonTree::find_nearest (photon_tree.rs:37-39) on top of the cube query: a cube of half width r that holds k photons
+// whose k-th smallest distance is <= r cannot miss a closer photon (anything outside the cube is farther than r along
+// one axis already), so the cube is doubled for the points that are not there yet.
+int rrt_photon_nearest(rrt_scene *s, int which, const float *positions, size_t n, uint32_t k, uint32_t *count, uint64_t *key, float *dist2) {
+    if (!s || which < 0 || which > 1 || !positions || !count || !key || !dist2) return fail(RRT_ERR_INVALID, "bad argument");
+    if (k == 0) return fail(RRT_ERR_INVALID, "k = 0");
+    if (!s->maps_built) return fail(RRT_ERR_STATE, "Photon map not built");
+    if (n == 0) return RRT_OK;
+    const PhotonIndex &X = s->index[which];
+    const uint64_t in_map = X.count;
+    std::vector<size_t> pending(n);
+    for (size_t i = 0; i < n; i++) pending[i] = i;
+    float r = X.inv_cell > 0.0f ? 0.5f / X.inv_cell : 0.1f;           // half a cell: the reference's own gather cube
+    const float r_max = X.inv_cell > 0.0f ? 64.0f / X.inv_cell : 6.4f;  // rrt_photon_query's limit
+    std::vector<float> pos, d2;
+    std::vector<uint32_t> cnt;
+    std::vector<uint64_t> keys;
+    for (;;) {
+        const size_t m = pending.size();
+        pos.resize(m * 3);
+        cnt.resize(m);
+        keys.assign(m * k, 0);
+        d2.assign(m * k, 0.0f);
+        for (size_t j = 0; j < m; j++) memcpy(&pos[j * 3], positions + pending[j] * 3, 3 * sizeof(float));
+        int rc = rrt_photon_query(s, which, pos.data(), m, r, k, cnt.data(), keys.data(), d2.data());
+        if (rc) return rc;
+        std::vector<size_t> next;
+        const float inside = r * r * (1.0f - 9.5367431640625e-7f);  // the cube test is on coordinates, the distances are rounded sums
+        for (size_t j = 0; j < m; j++) {
+            const uint32_t have = std::min<uint64_t>(cnt[j], k);
+            const bool all = cnt[j] >= in_map;                        // the whole map is inside the cube
+            const bool enough = cnt[j] >= k && d2[j * k + k - 1] <= inside;
+            if (all || enough) {
+                const size_t i = pending[j];
+                count[i] = have;
+                memcpy(key + i * k, &keys[j * k], have * sizeof(uint64_t));
+                memcpy(dist2 + i * k, &d2[j * k], have * sizeof(float));
+            } else {
+                next.push_back(pending[j]);
+            }
+        }
+        if (next.empty()) return RRT_OK;
+        if (r >= r_max) {
+            // Points whose k nearest photons are more than 64 index cells away (empty space, or k above what is nearby:
+            // shadow photons on the reference's infinite planes land millions of units out).  The grid has nothing to offer
+            // there: these few points are searched exhaustively on the host, same arithmetic, same order.
+            if (in_map > (1ull << 26)) return fail(RRT_ERR_LIMIT, "find_nearest: query point more than 64 index cells from its k nearest photons in a map above 2^26 records");
+            std::vector<float4> all_pos(in_map);
+            std::vector<uint64_t> all_key(in_map);
+            RRT_HIP(hipMemcpy(all_pos.data(), X.pos.p, in_map * sizeof(float4), hipMemcpyDeviceToHost));
+            RRT_HIP(hipMemcpy(all_key.data(), X.meta.p, in_map * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            std::vector<std::pair<float, uint64_t>> cand(in_map);
+            for (size_t i : next) {
+                const f3 p = mk3(positions[i * 3], positions[i * 3 + 1], positions[i * 3 + 2]);
+                for (uint64_t j = 0; j < in_map; j++)
+                    cand[j] = {lensq3(mk3(all_pos[j].x, all_pos[j].y, all_pos[j].z) - p), all_key[j]};
+                const size_t have = std::min<uint64_t>(k, in_map);
+                std::partial_sort(cand.begin(), cand.begin() + have, cand.end());  // (distance, key) ascending
+                count[i] = (uint32_t)have;
+                for (size_t j = 0; j < have; j++) {
+                    dist2[i * k + j] = cand[j].first;
+                    key[i * k + j] = cand[j].second;
+                }
+            }
+            return RRT_OK;
+        }
+        r = std::min(r * 2.0f, r_max);
+        pending.swap(next);
+    }
+}
+
 // ---- photon-map files (keep the maps between runs, re-render without re-shooting) ----
 // Layout, little endian: "RRTPMAP1", u32 version (1), u32 bytes per record (56), u64 seed, u64 count[2], then per map
 // pos[count] float4 (w = type), incident[count] float4, intensity[count] float4, meta[count] u64, in canonical order.

@@ -238,6 +238,42 @@ def test_photon_query_matches_get_n_within_radius(repo):
             assert gpu.photon_query(0, pts, 0.1, 0)[0].max() > 20
 
 
+def test_photon_nearest_matches_find_nearest(repo):
+    """rrt_photon_nearest = PhotonTree::find_nearest (photon_tree.rs:37-39): the k photons closest to each point, against a
+    brute force over the whole map (the oracle's cube query with a cube that holds everything): keys and squared
+    distances bit-exact, for points on surfaces, in empty space far from any photon, and for k above the map's size."""
+    cpu, gpu, cam = pair(repo, "pm_caustics", 30000, 2000)
+    with pytest.raises(rrt.RrtError) as e:
+        gpu.photon_nearest(0, [[0, 0, 0]], 4)
+    assert e.value.code == abi.ERR_STATE
+    cpu.pre_render(13)
+    gpu.pre_render(13)
+    cam.width = cam.height = 16
+    rays = [rrt.camera_ray(cam, x, y) for y in range(16) for x in range(16)]
+    hit = cpu.trace([r[0] for r in rays], [r[1] for r in rays])
+    pts = hit["position"][hit["object_id"] != abi.MISS]
+    rng = np.random.default_rng(9)
+    pts = np.concatenate([pts, rng.uniform(-2.5, 2.5, (60, 3)).astype(np.float32)])   # the second lot floats in mid-air
+    for which in (0, 1):
+        total = len(cpu.photon_read(which)["key"])
+        for k in (1, 7, 50):
+            cg, kg, dg = gpu.photon_nearest(which, pts, k)
+            cc, kc, dc = cpu.photon_query_list(which, pts, 1.0e6, k)        # everything is inside this cube
+            assert np.array_equal(cg, np.minimum(cc, k))
+            m = min(k, total)
+            assert np.array_equal(bits(dg[:, :m]), bits(dc[:, :m])), (which, k)
+            assert np.array_equal(kg[:, :m], kc[:, :m]), (which, k)
+    few = pair(repo, "pm_caustics", 40, 0)[1]
+    few.pre_render(1)
+    n = few.photon_count(0)
+    c, k_, d_ = few.photon_nearest(0, pts[:3], n + 5)                       # more than the map holds: all of it, sorted
+    assert (c == n).all() and np.all(np.diff(d_[:, :n], axis=1) >= 0)
+    far = np.array([[500.0, 500.0, 500.0], [-3000.0, 10.0, 0.0]], np.float32)  # nothing within 64 index cells: exhaustive path
+    cg, kg, dg = gpu.photon_nearest(0, far, 5)
+    cc, kc, dc = cpu.photon_query_list(0, far, 1.0e7, 5)
+    assert np.array_equal(bits(dg), bits(dc)) and np.array_equal(kg, kc)
+
+
 def test_scene2_at_the_reference_settings_matches_the_committed_render(repo):
     """render/rgb.ppm is one unseeded photon-mapped run of scene2 (5 M + 10 k photons, 1024^2) with the author's
     ffmpeg-decoded textures; render/rgb.png, a second run, differs from it by MAE 1.87/255, PSNR 37.05 dB
