@@ -256,6 +256,8 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
             F.bvh_depth = std::max(F.bvh_depth, depth);
             mi.node_count = (uint32_t)nodes.size();
             F.nodes.insert(F.nodes.end(), nodes.begin(), nodes.end());
+            F.tris.reserve(F.tris.size() + n);
+            F.tri_index.reserve(F.tri_index.size() + n);
             for (uint32_t k = 0; k < n; k++) {
                 const float *p = o.tri_pos.data() + (size_t)order[k] * 9;
                 f3 a = mk3(p[0], p[1], p[2]), b = mk3(p[3], p[4], p[5]), c = mk3(p[6], p[7], p[8]);
