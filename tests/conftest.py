@@ -11,6 +11,7 @@ for p in (REPO, os.path.join(REPO, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU test that takes about a minute (the oracle at the reference's full settings)")
 
 
 @pytest.fixture(scope="session")

@@ -35,12 +35,6 @@ def test_photon_maps_and_frames_match_oracle(repo, name, photons, caustic):
     gpu.pre_render(7)
     for which in (0, 1):
         pc, pg = cpu.photon_read(which), gpu.photon_read(which)
-        if name == "pm_diffuse":
-            # the wood sphere's normal map is addressed through atan2f/acosf: a one-ulp libm difference can change a
-            # bounce, after which that photon's path differs.  Compare as sets with a tolerance.
-            common = np.intersect1d(pc["key"], pg["key"]).size
-            assert common >= 0.995 * max(len(pc["key"]), len(pg["key"]))
-            continue
         assert np.array_equal(pc["key"], pg["key"])           # same records, same canonical order
         assert np.array_equal(pc["type"], pg["type"])
         for k in ("position", "incident", "intensity"):
@@ -55,9 +49,8 @@ def test_photon_maps_and_frames_match_oracle(repo, name, photons, caustic):
     # the gather adds the same photons in a different order (cell order vs sorted by distance): rounding only
     assert dq.mean() < 0.05 and (dq > 1).mean() < 1e-3, (dq.mean(), dq.max())
     sg, sc = gpu.stats(), cpu.stats()
-    if name != "pm_diffuse":
-        assert sg["photons_gathered"] == sc["photons_gathered"] and sg["gather_queries"] == sc["gather_queries"]
-        assert sg["rays_secondary"] == sc["rays_secondary"]
+    assert sg["photons_gathered"] == sc["photons_gathered"] and sg["gather_queries"] == sc["gather_queries"]
+    assert sg["rays_secondary"] == sc["rays_secondary"]
 
 
 def test_heavy_radiance_estimates_gathered_by_whole_waves(repo):
@@ -274,22 +267,23 @@ def test_photon_nearest_matches_find_nearest(repo):
     assert np.array_equal(bits(dg), bits(dc)) and np.array_equal(kg, kc)
 
 
-def test_scene2_at_the_reference_settings_matches_the_committed_render(repo):
-    """render/rgb.ppm is one unseeded photon-mapped run of scene2 (5 M + 10 k photons, 1024^2) with the author's
-    ffmpeg-decoded textures; render/rgb.png, a second run, differs from it by MAE 1.87/255, PSNR 37.05 dB
-    (SURVEY.md §4).  Stated tolerance for this build under seed 1: MAE < 3.0/255 and PSNR > 33 dB (looser than the
-    reference's self-noise because two textures are re-decoded with PIL); depth must reproduce render/depth.ppm."""
+def test_scene2_at_the_reference_settings_lies_inside_the_reference_noise_envelope(repo):
+    """render/rgb.ppm and render/rgb.png are two unseeded photon-mapped runs of scene2 (5 M + 10 k photons, 1024^2).
+    Their per-block difference is the reference's own noise; this build's frame under seed 1 must lie inside K x that
+    envelope block by block and object by object (tests/golden_envelope.py: K = 2, stated there with the separate
+    allowance for the two textures re-decoded with PIL).  The oracle passes the same check on the CPU
+    (tests/test_oracle_golden_render.py).  Depth must reproduce render/depth.ppm."""
     from PIL import Image
+
+    import golden_envelope as ge
 
     gpu, cam = rrt.Scene.load(os.path.join(repo, "assets/scenes/scene2.txt"))
     assert gpu.mode == abi.MODE_PHOTON and (cam.width, cam.height) == (1024, 1024)
     gpu.pre_render(1)
     rgb, depth, ids = gpu.render(cam)
-    ref = np.asarray(Image.open(os.path.join(repo, "tests/golden/render/rgb.ppm"))).astype(int)
-    d = np.abs(rrt.quantise(rgb).astype(int) - ref)
-    mae = d.mean()
-    psnr = 10 * np.log10(255.0 ** 2 / (d.astype(float) ** 2).mean())
-    assert mae < 3.0 and psnr > 33.0, (mae, psnr)
+    m = ge.check(rrt.quantise(rgb), ids)
+    print("golden envelope:", m)
+    assert m["mae_vs_png"] < m["mae_reference_runs"] + 0.1, m     # as close to the second run as the first run is
     dref = np.asarray(Image.open(os.path.join(repo, "tests/golden/render/depth.ppm")))
     assert np.array_equal(rrt.quantise(depth), dref)
     st = gpu.stats()
