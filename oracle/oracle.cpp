@@ -171,8 +171,10 @@ struct Sphere : Object {
         V3 position = ray.position + ray.direction * distance;
         V3 n = normalised(position - centre);
         if (dot(n, ray.direction) > 0.0f) n = -n;
-        float theta = atan2f(n.x, n.z) + PI_F;
-        float phi = acosf(-n.y);
+        // Rust's f32::atan2 / acos call the platform libm, whose f32 results differ between implementations by an ulp.
+        // The oracle pins them as the correctly rounded value: evaluate in f64, round to f32 once.
+        float theta = (float)std::atan2((double)n.x, (double)n.z) + PI_F;
+        float phi = (float)std::acos((double)-n.y);
         float u = theta / (2.0f * PI_F);
         float v = (PI_F - phi) / PI_F;
         V3 nm;
@@ -445,7 +447,7 @@ struct Phong : Material {  // phong_material.rs:12-60, 96-106
     }
     Colour specular(const Hit &hit, V3 ldir, V3 viewer) const {
         V3 refl = normalised(reflection(hit.normal, ldir));
-        float s = powf(fmaxf(dot(viewer, refl), 0.0f), shininess);
+        float s = (float)std::pow((double)fmaxf(dot(viewer, refl), 0.0f), (double)shininess);  // correctly rounded powf, as above
         return white() * s;
     }
     Colour compute_once(const Env &, const Ray &, const Hit &hit, int) const override {

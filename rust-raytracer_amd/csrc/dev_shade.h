@@ -31,7 +31,8 @@ __device__ __forceinline__ f3 phong_diffuse(f3 colour, const HitAttr &h, f3 ldir
 // phong_material.rs:30-34
 __device__ __forceinline__ f3 phong_specular(const HitAttr &h, f3 ldir, f3 viewer, float shininess) {
     f3 refl = norm3(reflect3(h.normal, ldir));
-    float s = powf(fmaxf(dot3(viewer, refl), 0.0f), shininess);
+    // through f64, rounded to f32 once: a correctly rounded powf on both sides of the parity check (see eval_hit)
+    float s = (float)pow((double)fmaxf(dot3(viewer, refl), 0.0f), (double)shininess);
     return mk3(1.0f * s, 1.0f * s, 1.0f * s);
 }
 

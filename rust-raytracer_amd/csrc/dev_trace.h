@@ -758,8 +758,10 @@ __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t
             h.position = o + d * t;
             f3 n = norm3(h.position - c);
             if (dot3(n, d) > 0.0f) n = -n;
-            float theta = atan2f(n.x, n.z) + PI_F;
-            float phi = acosf(-n.y);
+            // libm calls go through f64 and are rounded to f32 once (= a correctly rounded atan2f / acosf up to
+            // double-rounding ties): x86 glibc and the device's ocml then agree, which their f32 versions do not
+            float theta = (float)atan2((double)n.x, (double)n.z) + PI_F;
+            float phi = (float)acos((double)-n.y);
             h.u = theta / (2.0f * PI_F);
             h.v = (PI_F - phi) / PI_F;
             h.has_tex = true;
