@@ -362,6 +362,19 @@ int rrt_photon_save(rrt_scene *s, const char *path);
 int rrt_photon_load(rrt_scene *s, const char *path);
 int rrt_photon_build(rrt_scene *s);
 
+/* rrt_trace for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, results and error behaviour as
+ * rrt_trace (host pointers, any output may be NULL), but every byte of device memory the call needs beyond the scene
+ * (staging of the ray and result arrays, the error word, the traversal counters) lives in one static device array of
+ * 4.25 MiB that each GPU holds from library load to process exit: the call makes no hipMalloc / hipFree.  At most
+ * RRT_NOALLOC_MAX_RAYS rays per call (RRT_ERR_LIMIT above, nothing is traced).  All calls on one GPU share that
+ * GPU's array: calls that overlap in time on one GPU (from several threads or scene handles) race; one after the
+ * other they are independent.  Needs rrt_pre_render first (that call does allocate: it puts the scene into HBM). */
+#define RRT_NOALLOC_MAX_RAYS 65536
+int rrt_trace_noalloc(rrt_scene *s, const float *origins, const float *directions, size_t n,
+                      uint32_t *object_id, uint32_t *prim_id, float *distance, float *position,
+                      float *normal, float *uv);
+
 /* the render fields are those of the CALLING THREAD's last render call on this handle (concurrent callers each see
  * their own frame); after anything else changed the handle's statistics, the handle's latest values               */
 int rrt_get_stats(const rrt_scene *s, rrt_stats *out);

@@ -91,6 +91,7 @@ _sig("rrt_render_device", C.c_int, C.c_void_p, C.POINTER(Camera), C.c_uint32, C.
 _sig("rrt_raytrace", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _f32p, _f32p, _u32p)
 _sig("rrt_trace", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _u32p, _u32p, _f32p, _f32p, _f32p, _f32p)
 _sig("rrt_shadowtrace", C.c_int, C.c_void_p, _f32p, _f32p, _f32p, C.c_size_t, _u8p)
+_sig("rrt_trace_noalloc", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _u32p, _u32p, _f32p, _f32p, _f32p, _f32p)
 _sig("rrt_photon_begin", C.c_int, C.c_void_p, C.c_uint64)
 _sig("rrt_photon_shoot", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64)
 _sig("rrt_photon_build", C.c_int, C.c_void_p)
@@ -278,7 +279,8 @@ class Scene:
         check(lib.rrt_raytrace(self._h, _fp(o), _fp(d), n, _fp(rgb), _fp(depth), ids.ctypes.data_as(_u32p)))
         return rgb, depth, ids
 
-    def trace(self, origins, directions):
+    def trace(self, origins, directions, noalloc=False):
+        """Environment::trace, batched (rrt_trace; noalloc=True: rrt_trace_noalloc, at most NOALLOC_MAX_RAYS rays)."""
         o, d = _f32(origins, (-1, 3)), _f32(directions, (-1, 3))
         n = o.shape[0]
         out = {
@@ -290,7 +292,7 @@ class Scene:
             "uv": np.zeros((n, 2), np.float32),
         }
         check(
-            lib.rrt_trace(
+            (lib.rrt_trace_noalloc if noalloc else lib.rrt_trace)(
                 self._h, _fp(o), _fp(d), n, out["object_id"].ctypes.data_as(_u32p), out["prim_id"].ctypes.data_as(_u32p),
                 _fp(out["distance"]), _fp(out["position"]), _fp(out["normal"]), _fp(out["uv"]),
             )

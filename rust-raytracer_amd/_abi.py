@@ -9,6 +9,7 @@ OBJ_PLANE, OBJ_SPHERE, OBJ_CUBOID, OBJ_QUADRATIC, OBJ_MESH, OBJ_CSG = range(6)
 CSG_UNION, CSG_INTERSECTION, CSG_DIFFERENCE = range(3)
 LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_DIRPOINT = range(3)
 MISS = 0xFFFFFFFF
+NOALLOC_MAX_RAYS = 65536  # RRT_NOALLOC_MAX_RAYS
 
 
 BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
