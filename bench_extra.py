@@ -52,16 +52,42 @@ def teapot_grid(nx=13, nz=13, spacing=34.0):
     return np.ascontiguousarray(np.concatenate(P), np.float32), np.ascontiguousarray(np.concatenate(N), np.float32)
 
 
-def build_mesh_scene(rrt, smooth=True, bvh_builder=0):
+def build_mesh_scene(rrt, smooth=True, bvh_builder=0, variant="phong"):
+    """variant: "phong" (BASELINE configs[3]: Monochrome teapots, primary + shadow rays), "nolight" (the same without the
+    light: primary rays only), "mirror" (teapots `Simple` = Compound[Monochrome, Global(reflect 0.6)], floor mirror too:
+    reflection rays bounce between the teapots and the floor, compound_material.rs:39-49) and "glass" (`Transparent`,
+    ior 1.5: reflection + refraction rays, compound_material.rs:51-63): secondary rays that walk the BVH incoherently."""
     abi = rrt._abi
     pos, nrm = teapot_grid()
     s = rrt.Scene(params=rrt.default_params(bvh_builder=bvh_builder))
-    m = abi.MaterialDesc()
-    m.kind = abi.MAT_MONOCHROME
-    m.colour[:] = (0.8, 0.6, 0.2)
-    m.ambient, m.shininess = 0.1, 50.0
-    m.diffuse_tex = m.normal_tex = -1
-    mat = s.add_material(m)
+
+    def mono(colour, ambient, shininess):
+        m = abi.MaterialDesc()
+        m.kind = abi.MAT_MONOCHROME
+        m.colour[:] = colour
+        m.ambient, m.shininess = ambient, shininess
+        m.diffuse_tex = m.normal_tex = -1
+        return s.add_material(m)
+
+    def compound(colour, reflect, refract, ior):
+        g = abi.MaterialDesc()
+        g.kind = abi.MAT_GLOBAL
+        g.reflect_weight, g.refract_weight, g.ior = reflect, refract, ior
+        g.diffuse_tex = g.normal_tex = -1
+        c = abi.MaterialDesc()
+        c.kind = abi.MAT_COMPOUND
+        c.n_parts = 2
+        c.parts[0], c.parts[1] = mono(colour, 0.1, 100.0), s.add_material(g)
+        c.diffuse_tex = c.normal_tex = -1
+        return s.add_material(c)
+
+    if variant == "mirror":
+        mat, floor_mat = compound((0.8, 0.6, 0.2), 0.6, 0.0, 1.0), compound((0.3, 0.5, 0.3), 0.4, 0.0, 1.0)
+    elif variant == "glass":
+        t = 0.7
+        mat, floor_mat = compound((0.8 * (1 - t), 0.6 * (1 - t), 0.2 * (1 - t)), t, t, 1.5), mono((0.3, 0.5, 0.3), 0.1, 100.0)
+    else:
+        mat, floor_mat = mono((0.8, 0.6, 0.2), 0.1, 50.0), mono((0.3, 0.5, 0.3), 0.1, 100.0)
     d = abi.ObjectDesc()
     d.kind = abi.OBJ_MESH
     d.material = mat
@@ -70,21 +96,17 @@ def build_mesh_scene(rrt, smooth=True, bvh_builder=0):
     d.n_triangles = pos.shape[0]
     d.smooth = 1 if smooth else 0
     s.add_object(s.object_define(d))
-    f = abi.MaterialDesc()
-    f.kind = abi.MAT_MONOCHROME
-    f.colour[:] = (0.3, 0.5, 0.3)
-    f.ambient, f.shininess = 0.1, 100.0
-    f.diffuse_tex = f.normal_tex = -1
     floor = abi.ObjectDesc()
     floor.kind = abi.OBJ_PLANE
-    floor.material = s.add_material(f)
+    floor.material = floor_mat
     floor.v[:9] = (0, 0, 0, 0, 0, 1, 0, 1, 0)
     s.add_object(s.object_define(floor))
-    l = abi.LightDesc()
-    l.kind = abi.LIGHT_POINT
-    l.position[:] = (0.0, 400.0, -300.0)
-    l.colour[:] = (1.2, 1.2, 1.2)
-    s.add_light(l)
+    if variant != "nolight":
+        l = abi.LightDesc()
+        l.kind = abi.LIGHT_POINT
+        l.position[:] = (0.0, 400.0, -300.0)
+        l.colour[:] = (1.2, 1.2, 1.2)
+        s.add_light(l)
     cam = rrt.make_camera(3840, 2160, math.radians(40.0), (0.0, 260.0, -420.0), (0.0, 0.55, 1.0))  # file-space lookat: +y looks down (full_camera.rs:31-34)
     return s, cam, pos.shape[0]
 

@@ -63,8 +63,9 @@ typedef struct rrt_params {
                                            The reference has no acceleration structure (polymesh_object.rs:219-236) */
     uint32_t gather_heavy_threshold;    /* photon mode: a radiance estimate whose two query boxes hold more candidate
                                            records than this is gathered by a whole wave in a second kernel instead of by
-                                           its lane (0 = default 2048; 0xFFFFFFFF = never).  Same photons; the f32 sums
-                                           are added in another (fixed) order                                           */
+                                           its lane.  0 = default: derived from the photon maps at rrt_photon_build (4 x the
+                                           candidate records of a typical query, at least 2048); 0xFFFFFFFF = never.  Same
+                                           photons; the f32 sums are added in another (fixed) order                     */
     uint32_t reserved[6];
 } rrt_params;
 enum rrt_bvh_builder { RRT_BVH_HOST_SAH = 0, RRT_BVH_DEVICE_LBVH = 1 };
@@ -323,20 +324,27 @@ int rrt_photon_read(rrt_scene *s, int which, float *position, float *incident, f
 int rrt_photon_begin(rrt_scene *s, uint64_t seed);
 int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t count);
 int rrt_photon_caustic_count(rrt_scene *s, int light, uint64_t *count);
-/* seeds = [count][4] f32 (position xyz of the pass-1 caustic photon + its incident packed is
- * not needed: Point lights aim at `incident`, DirPoint at `position`, so both are exported):
- * pos [count][3], incident [count][3], key [count].  Device pointers.                       */
-int rrt_photon_caustic_export_device(rrt_scene *s, int light, float *pos_dev, float *incident_dev,
+/* Exchange arrays are float4 records (16 bytes each), as the library keeps them in HBM: the collective moves them
+ * without repacking.  Device pointers; the caller allocates count * 16 bytes per float4 array and count * 8 per key /
+ * meta array, count from the matching *_count call.
+ * Caustic seeds of one light (what pass 2 aims at: Point lights use `incident`, DirPoint lights `position`,
+ * point_light.rs:117-121, directional_point_light.rs:110-115):
+ *   pos4 [count][4] f32 = position.xyz, w = photon type as uint bits;  incident4 [count][4] f32 = incident.xyz, w unused;
+ *   key [count] u64 = the seed photon's record key.                                              */
+int rrt_photon_caustic_export_device(rrt_scene *s, int light, float *pos4_dev, float *incident4_dev,
                                      uint64_t *key_dev);
-int rrt_photon_caustic_import_device(rrt_scene *s, int light, const float *pos_dev,
-                                     const float *incident_dev, const uint64_t *key_dev, uint64_t count);
+int rrt_photon_caustic_import_device(rrt_scene *s, int light, const float *pos4_dev,
+                                     const float *incident4_dev, const uint64_t *key_dev, uint64_t count);
 int rrt_photon_local_count(rrt_scene *s, int which, uint64_t *count);
-/* SoA export of this rank's records: pos/incident/intensity [count][3] f32, meta [count] u64
- * (key in the low 56 bits, (light*2+pass) in bits 56..62 — see DESIGN.md)                     */
-int rrt_photon_export_device(rrt_scene *s, int which, float *pos_dev, float *incident_dev,
-                             float *intensity_dev, uint64_t *meta_dev);
-int rrt_photon_import_device(rrt_scene *s, int which, const float *pos_dev, const float *incident_dev,
-                             const float *intensity_dev, const uint64_t *meta_dev, uint64_t count);
+/* SoA export of this rank's records of map `which`:
+ *   pos4 [count][4] f32 = position.xyz, w = rrt_photon_type as uint bits;  incident4 [count][4] f32 = incident.xyz, w unused;
+ *   intensity4 [count][4] f32 = intensity.rgb, w unused;
+ *   meta [count] u64 = record key in the low 56 bits, (light * 2 + pass) in bits 56..62.
+ * 56 bytes per record in all.                                                                     */
+int rrt_photon_export_device(rrt_scene *s, int which, float *pos4_dev, float *incident4_dev,
+                             float *intensity4_dev, uint64_t *meta_dev);
+int rrt_photon_import_device(rrt_scene *s, int which, const float *pos4_dev, const float *incident4_dev,
+                             const float *intensity4_dev, const uint64_t *meta_dev, uint64_t count);
 
 /* PhotonTree::get_within_distance and get_n_within_radius (core/photon_tree.rs:15-35, 41-50), batched: for each of
  * the n query points the photons of map `which` (0 regular, 1 caustic) inside the closed cube of half width

@@ -81,6 +81,19 @@ __device__ __forceinline__ uint32_t node_pixel(uint32_t g, uint32_t width, uint3
     return full_rows * width + (r - wrem * full_rows);
 }
 
+// the ray of node i of the level being processed: generated from the camera (level 0 of a camera render) or read from
+// the level's queue
+__device__ __forceinline__ void level_ray(const TraceArgs &A, uint32_t i, f3 &o, f3 &d) {
+    if (A.level == 0 && A.cam.width != 0) {
+        uint32_t pixel = node_pixel(A.pixel_base + i, A.cam.width, A.band_rows);
+        camera_ray(A.cam, pixel % A.cam.width, A.y0 + pixel / A.cam.width, o, d);
+    } else {
+        float4 ro = A.cur.ray_o[i], rd = A.cur.ray_d[i];
+        o = mk3(ro.x, ro.y, ro.z);
+        d = mk3(rd.x, rd.y, rd.z);
+    }
+}
+
 #ifndef RRT_MIN_WAVES
 #define RRT_MIN_WAVES 3
 #endif
@@ -104,14 +117,7 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
     h.material = 0;
 
     if (active) {
-        if (A.level == 0 && A.cam.width != 0) {
-            uint32_t pixel = node_pixel(A.pixel_base + i, A.cam.width, A.band_rows);
-            camera_ray(A.cam, pixel % A.cam.width, A.y0 + pixel / A.cam.width, o, d);
-        } else {
-            float4 ro = A.cur.ray_o[i], rd = A.cur.ray_d[i];
-            o = mk3(ro.x, ro.y, ro.z);
-            d = mk3(rd.x, rd.y, rd.z);
-        }
+        level_ray(A, i, o, d);
         TraceResult tr;
         trace<FEAT>(S, o, d, lds, cnt, tr);
         if (tr.object != 0xFFFFFFFFu) {

@@ -435,6 +435,9 @@ int flatten_scene(rrt_scene *s) {
     D.lds_bytes = std::max(list_bytes, stack_bytes);
     if (D.lds_bytes > 160 * 1024) return fail(RRT_ERR_LIMIT, "per-block LDS need exceeds 160 KiB (BVH too deep)");
     D.flops_per_trace = F.flops;
+    if (getenv("RRT_BVH_INFO"))
+        fprintf(stderr, "rrt: %zu meshes, %zu triangles, %zu BVH nodes, depth %u, LDS %zu bytes per block\n", F.meshes.size(), F.tris.size(),
+                F.nodes.size(), F.bvh_depth, D.lds_bytes);
 
     std::vector<DevMaterial> mats;
     int rc = flatten_materials(s, mats, D.reflective);
@@ -601,8 +604,7 @@ void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, ui
     A.gather_half_width = s->params.gather_half_width;
     A.err = L.ctr + 63;
     A.stats = s->stats_dev.p;
-    A.heavy = L.heavy.p;  // null unless render_rays_impl decided to use the queue
-    A.heavy_capacity = (uint32_t)std::min<size_t>(L.heavy.cap, 0xFFFFFFFFu);
+    A.heavy = L.heavy.p;  // null unless render_rays_impl decided to use the queue; heavy_capacity is set per level
     A.heavy_threshold = s->params.gather_heavy_threshold ? s->params.gather_heavy_threshold : s->heavy_auto;
     A.out_rgb = rgb_dev;
     A.out_depth = depth_dev;
@@ -636,14 +638,12 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
         if (s->lanes[j]->levels.size() < n_levels + 1) s->lanes[j]->levels.resize(n_levels + 1);
     // photon mode: heavy radiance estimates are filed per level (lane counters [32 + level]) and gathered by whole waves
     const bool heavy_queue = s->mode == RRT_MODE_PHOTON && s->params.gather_heavy_threshold != 0xFFFFFFFFu && n_levels <= 30;
-    for (uint32_t j = 0; j < want_lanes; j++) {
-        if (heavy_queue) {  // sized for the chunk's pixels (deeper levels are smaller in practice); lanes that find the
-            // queue full gather for themselves
-            if ((rc = s->lanes[j]->heavy.ensure(std::min(chunk, n_pixels)))) return rc;
-        } else {
-            s->lanes[j]->heavy.release();
-        }
-    }
+    // The queue of a level holds one record per ray of that level (every query may be heavy), so it is sized from the
+    // level sizes below, never from the chunk: a level behind glass can hold more rays than the chunk has pixels, and a
+    // lane that found the queue full would gather for itself in another summation order (frames would then depend on
+    // atomics order).
+    if (!heavy_queue)
+        for (uint32_t j = 0; j < want_lanes; j++) s->lanes[j]->heavy.release();
 
     RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, (RRT_STAT_WORDS + 32) * sizeof(unsigned long long), stream));  // + lane 0's counters
     bool lane0_clean = true;
@@ -701,6 +701,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     if ((rc = L.levels[k].ensure(caps[k], n_lights, true))) return rc;
                 }
                 if ((rc = L.levels[n_run].ensure(1, n_lights, true))) return rc;
+                if (heavy_queue && (rc = L.heavy.ensure(*std::max_element(caps.begin(), caps.end())))) return rc;
                 if (!(j == 0 && lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), st));
                 if (j == 0) lane0_clean = false;
                 if (!cam)
@@ -717,6 +718,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     A.level = k;
                     A.next_count = L.ctr + (k + 1);
                     A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
+                    A.heavy_capacity = caps[k];
                     launch_trace_shade(A, D.lds_bytes, st);
                     launch_gather_heavy(A, st);
                 }
@@ -780,6 +782,11 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                 for (uint32_t k = 0; k < n_levels; k++) {
                     bool spawns = k + 1 < n_levels;
                     if (spawns && (rc = L.levels[k + 1].ensure(2 * counts[k], n_lights, true))) return rc;
+                    if (heavy_queue) {  // the stream is idle here (synchronised after the previous level): growing is safe
+                        if ((rc = L.heavy.ensure(counts[k]))) return rc;
+                        A.heavy = L.heavy.p;
+                        A.heavy_capacity = counts[k];
+                    }
                     A.cur = L.levels[k].view();
                     A.next = L.levels[k + 1].view();
                     A.count = counts[k];
@@ -1031,6 +1038,7 @@ rrt_scene *rrt_scene_create(int mode, const rrt_params *params) {
 void rrt_scene_destroy(rrt_scene *s) { delete s; }
 int rrt_scene_set_mode(rrt_scene *s, int mode) {
     if (!s || (mode != RRT_MODE_SCENE && mode != RRT_MODE_PHOTON)) return fail(RRT_ERR_INVALID, "bad mode");
+    drop_render_workers(s);  // workers copy mode and params when they are made: none may outlive a change
     s->mode = mode;
     return RRT_OK;
 }
@@ -1039,6 +1047,7 @@ int rrt_scene_set_params(rrt_scene *s, const rrt_params *params) {
     if (!s || !params) return fail(RRT_ERR_INVALID, "null argument");
     if (params->max_depth > 40 || params->max_vueon_depth > 40 || params->max_photon_bounces > 64)
         return fail(RRT_ERR_LIMIT, "max_depth/max_vueon_depth <= 40, max_photon_bounces <= 64");
+    drop_render_workers(s);  // see rrt_scene_set_mode
     s->params = *params;
     s->maps_built = false;
     return RRT_OK;
