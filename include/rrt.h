@@ -52,7 +52,7 @@ typedef struct rrt_params {
                                            this build stops a path after this many landings (64)    */
     uint32_t max_vueon_depth;           /* reference: unbounded (photon_scene.rs:329-352); deeper
                                            vueons return black here (default 12)                    */
-    uint32_t chunk_pixels;              /* pixels per wavefront-queue chunk (0 = default 1<<22)     */
+    uint32_t chunk_pixels;              /* pixels per wavefront-queue chunk (0 = default 1<<23)     */
     uint32_t render_streams;            /* HIP streams the chunks of a frame are spread over (0 or 1 =
                                            the caller's stream only, the default; at most 8).  Measured
                                            on MI355X: 2 / 4 / 8 streams are 9 / 21 / 100 % slower on the

@@ -6,6 +6,7 @@
 // reference's same-side test is evaluated at a rounded hit point that may sit a few ulps outside
 // the exact triangle).
 #include <math.h>
+#include <cmath>
 
 #include <algorithm>
 #include <vector>
@@ -224,6 +225,75 @@ void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order,
         nd.cnt[0] = L.left >= 0 ? 0 : L.count;
         nd.cnt[1] = R.left >= 0 ? 0 : R.count;
         nodes[k] = nd;
+    }
+}
+
+// The traversal's node format: the builders' f32 boxes rounded outward onto a 16-bit grid over the mesh's bounds.
+// Containment is checked in exact arithmetic: qbase + q * qscale is exact in double (24-bit x 16-bit product, 24-bit
+// addend), so "decoded lower face <= box lower face" holds for the real numbers the device's fma approximates; the
+// device's own rounding is covered by its pad (dev_trace.h, make_slabs).
+void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<BvhNodeQ> &out) {
+    const float lim = 1152921504606846976.0f;  // 2^60
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool wild = nodes.empty();
+    auto box_axis = [](const BvhNode &n, int a) -> const float4 & { return a == 0 ? n.lo_x_hi_x : (a == 1 ? n.lo_y_hi_y : n.lo_z_hi_z); };
+    for (const BvhNode &n : nodes)
+        for (int a = 0; a < 3; a++) {
+            const float4 &b = box_axis(n, a);
+            const float v[4] = {b.x, b.y, b.z, b.w};  // l.lo, r.lo, l.hi, r.hi
+            for (int c = 0; c < 2; c++) {
+                const float l = v[c], h = v[2 + c];
+                if (l > h) continue;  // empty child (bvh_build.cpp: a mesh of <= 4 triangles) or NaN
+                if (!(std::fabs(l) < lim) || !(std::fabs(h) < lim)) wild = true;
+                lo[a] = std::min(lo[a], l);
+                hi[a] = std::max(hi[a], h);
+            }
+            if (std::isnan(b.x) || std::isnan(b.y) || std::isnan(b.z) || std::isnan(b.w)) wild = true;
+        }
+    for (int a = 0; a < 3; a++)
+        if (!(lo[a] <= hi[a])) wild = true;
+    mi.wild = wild ? 1u : 0u;
+    mi.qmag = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        mi.qbase[a] = wild ? 0.0f : lo[a];
+        // a little more than extent / 65535, so that the top of the range decodes at or above hi; never 0
+        float sc = wild ? 0.0f : (float)(((double)hi[a] - (double)lo[a]) / 65535.0 * (1.0 + 1e-6));
+        if (!wild && !(sc > 0.0f)) sc = std::max(std::fabs(lo[a]), 1.0f) * 1e-7f;  // flat mesh on this axis
+        mi.qscale[a] = sc;
+        if (!wild) mi.qmag = std::max(mi.qmag, std::max(std::fabs(lo[a]), std::fabs(hi[a])) + (hi[a] - lo[a]));
+    }
+    auto q_down = [&](float v, int a) -> uint32_t {
+        if (wild) return 0u;
+        const double base = mi.qbase[a], sc = mi.qscale[a];
+        double q = std::floor(((double)v - base) / sc);
+        q = std::min(std::max(q, 0.0), 65535.0);
+        while (q > 0.0 && base + q * sc > (double)v) q -= 1.0;
+        return (uint32_t)q;
+    };
+    auto q_up = [&](float v, int a) -> uint32_t {
+        if (wild) return 65535u;
+        const double base = mi.qbase[a], sc = mi.qscale[a];
+        double q = std::ceil(((double)v - base) / sc);
+        q = std::min(std::max(q, 0.0), 65535.0);
+        while (q < 65535.0 && base + q * sc < (double)v) q += 1.0;
+        return (uint32_t)q;
+    };
+    out.resize(nodes.size());
+    for (size_t k = 0; k < nodes.size(); k++) {
+        const BvhNode &n = nodes[k];
+        BvhNodeQ &o = out[k];
+        for (int a = 0; a < 3; a++) {
+            const float4 &b = box_axis(n, a);
+            const float v[4] = {b.x, b.y, b.z, b.w};
+            for (int c = 0; c < 2; c++) {
+                const float l = v[c], h = v[2 + c];
+                // an empty child stays empty (lower face above upper face) unless the mesh is wild
+                const uint32_t ql = (l > h && !wild) ? 65535u : q_down(l, a), qh = (l > h && !wild) ? 0u : q_up(h, a);
+                o.q[2 * a + c] = ql | (qh << 16);
+            }
+        }
+        for (int c = 0; c < 2; c++)
+            o.child[c] = n.child[c] >= 0 ? n.child[c] : -(int32_t)((((uint32_t)(~n.child[c])) << 4) | (n.cnt[c] & 15u)) - 1;
     }
 }
 

@@ -68,8 +68,20 @@ struct MeshInfo {
     uint32_t smooth;
     uint32_t has_normals;
     uint32_t nrm_first;  // first triangle of this mesh in tri_normals
+    // grid of the quantised node boxes (BvhNodeQ): coordinate = qbase + q * qscale, q in 0..65535
+    float qbase[3], qscale[3];
+    float qmag;     // largest |coordinate| of the grid + its largest extent: scales the traversal's rounding pad
+    uint32_t wild;  // 1: a coordinate is not finite or beyond 2^60: the boxes are not used, every node is visited
 };
-// BVH2 node, 64 B: both children's boxes, so one node fetch decides both descents.
+// BVH2 node as the traversal reads it, 32 B (two 16-byte loads per lane and visit): both children's boxes on the
+// mesh's 16-bit grid (lower faces rounded down, upper faces rounded up: the decoded box contains the builder's box).
+//   q[2a + c] = lo | hi << 16 of child c (0 left, 1 right) on axis a
+//   child >= 0 -> inner node (mesh-local index); child < 0 -> leaf: -(child + 1) = first triangle slot << 4 | count
+struct BvhNodeQ {
+    uint32_t q[6];
+    int32_t child[2];
+};
+// BVH2 node as the builders emit it (host SAH, device LBVH), 64 B: both children's boxes in f32.
 // child < 0  -> leaf: ~child = first triangle slot (mesh-local, in BVH order), count in cnt
 struct BvhNode {
     float4 lo_x_hi_x;  // l.lo.x, r.lo.x, l.hi.x, r.hi.x
@@ -121,7 +133,7 @@ struct DevScene {
     const TriHot *tris;        // BVH order
     const uint32_t *tri_index; // BVH order -> original triangle index
     const float *tri_normals;  // [orig tri][3][3], only for smooth meshes
-    const BvhNode *nodes;
+    const BvhNodeQ *nodes;
     const DevMaterial *materials;
     const DevTexture *textures;
     const uchar4 *texels8;

@@ -191,30 +191,57 @@ __device__ __forceinline__ bool tri_test(const TriHot &T, f3 o, f3 d, float &t, 
     return dot3(ab_n, bc_n) > 0.0f && dot3(bc_n, ca_n) > 0.0f;
 }
 
-// Conservative ray/box slab test against both children of a node.  Three margins make sure the
-// BVH can only prune what the reference's exact test would reject anyway:
-//  * boxes are padded on the host by 2^-16 of their coordinate magnitude (bvh_build.cpp);
-//  * the box is grown by 2^-20 of the ray origin's magnitude (`op` = origin + e is used against the
-//    lower faces, `om` = origin - e against the upper faces), covering the rounding of o + d*t;
-//  * the [near, far] interval is widened by a relative 2^-20, covering the slab arithmetic itself.
-__device__ __forceinline__ void box2_test(const BvhNode &N, f3 op, f3 om, f3 inv, float tmax, bool &hit_l, bool &hit_r,
-                                          float &near_l, float &near_r) {
-    float lx0 = (N.lo_x_hi_x.x - op.x) * inv.x, lx1 = (N.lo_x_hi_x.z - om.x) * inv.x;
-    float rx0 = (N.lo_x_hi_x.y - op.x) * inv.x, rx1 = (N.lo_x_hi_x.w - om.x) * inv.x;
-    float ly0 = (N.lo_y_hi_y.x - op.y) * inv.y, ly1 = (N.lo_y_hi_y.z - om.y) * inv.y;
-    float ry0 = (N.lo_y_hi_y.y - op.y) * inv.y, ry1 = (N.lo_y_hi_y.w - om.y) * inv.y;
-    float lz0 = (N.lo_z_hi_z.x - op.z) * inv.z, lz1 = (N.lo_z_hi_z.z - om.z) * inv.z;
-    float rz0 = (N.lo_z_hi_z.y - op.z) * inv.z, rz1 = (N.lo_z_hi_z.w - om.z) * inv.z;
-    // fminf/fmaxf drop NaNs (0 * inf when the origin lies on a slab plane of a parallel ray)
+// Conservative ray/box slab test against both children of a node.  The BVH may only prune what the reference's exact
+// triangle test would reject anyway; three margins see to that:
+//  * the builders pad every box by 2^-16 of its coordinate magnitude (bvh_build.cpp, bvh_lbvh.h) and the quantiser
+//    rounds lower faces down and upper faces up on the mesh's 16-bit grid (quantise_bvh);
+//  * the box is grown by e = 2^-20 of (the ray origin's magnitude + the grid's magnitude): lower faces are tested
+//    against origin + e, upper faces against origin - e.  That covers the rounding of o + d*t in the reference's hit
+//    point and of the slab distances here, each of which is ONE fma on the quantised coordinate:
+//        t = q * (qscale / d) + (qbase - (o +- e)) / d
+//  * the far end of the [near, far] interval is widened by a relative 2^-18 (1/d is a 1-ulp reciprocal).
+// Reciprocals are clamped to +-2^60 and rays or meshes with coordinates beyond 2^60 (or not finite) skip the pruning
+// altogether (every node is visited), so no inf - inf can turn a slab distance into a NaN that min/max would drop on the
+// wrong side.  None of this arithmetic is part of the parity contract (it only prunes): it may fuse and approximate.
+struct RaySlabs {
+    f3 a, blo, bhi;
+};
+__device__ __forceinline__ RaySlabs make_slabs(const MeshInfo &M, f3 o, f3 d) {
+    const float lim = 1152921504606846976.0f;  // 2^60
+    const float omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    RaySlabs r;
+    if (M.wild || !(omax < lim)) {  // no pruning: every slab distance is 0, every box "hit"
+        r.a = r.blo = r.bhi = mk3(0.0f, 0.0f, 0.0f);
+        return r;
+    }
+    f3 inv = mk3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -lim, lim), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -lim, lim),
+                 __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -lim, lim));
+    const float e = (omax + M.qmag) * 9.5367431640625e-7f;  // 2^-20
+    r.a = mk3(M.qscale[0] * inv.x, M.qscale[1] * inv.y, M.qscale[2] * inv.z);
+    r.blo = mk3((M.qbase[0] - (o.x + e)) * inv.x, (M.qbase[1] - (o.y + e)) * inv.y, (M.qbase[2] - (o.z + e)) * inv.z);
+    r.bhi = mk3((M.qbase[0] - (o.x - e)) * inv.x, (M.qbase[1] - (o.y - e)) * inv.y, (M.qbase[2] - (o.z - e)) * inv.z);
+    return r;
+}
+__device__ __forceinline__ void box2_test(const BvhNodeQ &N, const RaySlabs &R, float tmax, bool &hit_l, bool &hit_r, float &near_l,
+                                          float &near_r) {
+#define RRT_QLO(w) ((float)((w) & 0xFFFFu))
+#define RRT_QHI(w) ((float)((w) >> 16))
+    float lx0 = __builtin_fmaf(RRT_QLO(N.q[0]), R.a.x, R.blo.x), lx1 = __builtin_fmaf(RRT_QHI(N.q[0]), R.a.x, R.bhi.x);
+    float rx0 = __builtin_fmaf(RRT_QLO(N.q[1]), R.a.x, R.blo.x), rx1 = __builtin_fmaf(RRT_QHI(N.q[1]), R.a.x, R.bhi.x);
+    float ly0 = __builtin_fmaf(RRT_QLO(N.q[2]), R.a.y, R.blo.y), ly1 = __builtin_fmaf(RRT_QHI(N.q[2]), R.a.y, R.bhi.y);
+    float ry0 = __builtin_fmaf(RRT_QLO(N.q[3]), R.a.y, R.blo.y), ry1 = __builtin_fmaf(RRT_QHI(N.q[3]), R.a.y, R.bhi.y);
+    float lz0 = __builtin_fmaf(RRT_QLO(N.q[4]), R.a.z, R.blo.z), lz1 = __builtin_fmaf(RRT_QHI(N.q[4]), R.a.z, R.bhi.z);
+    float rz0 = __builtin_fmaf(RRT_QLO(N.q[5]), R.a.z, R.blo.z), rz1 = __builtin_fmaf(RRT_QHI(N.q[5]), R.a.z, R.bhi.z);
+#undef RRT_QLO
+#undef RRT_QHI
     float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
     float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
     float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
     float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
-    const float k = 9.5367431640625e-7f;  // 2^-20
-    float lnc = ln - fabsf(ln) * k, lfc = lf + fabsf(lf) * k;
-    float rnc = rn - fabsf(rn) * k, rfc = rf + fabsf(rf) * k;
-    hit_l = lnc <= lfc && lfc >= 0.0f && lnc <= tmax;
-    hit_r = rnc <= rfc && rfc >= 0.0f && rnc <= tmax;
+    const float K = 1.000003814697265625f;  // 1 + 2^-18
+    // hit: the interval [max(near, 0), min(far, tmax)] is not empty once its far end is widened
+    hit_l = lf >= 0.0f && ln <= fminf(lf, tmax) * K;
+    hit_r = rf >= 0.0f && rn <= fminf(rf, tmax) * K;
     near_l = ln;
     near_r = rn;
 }
@@ -224,15 +251,13 @@ __device__ __forceinline__ void box2_test(const BvhNode &N, f3 op, f3 om, f3 inv
 // the best distance so far: a farther mesh hit could not win anyway).  Returns the BVH slot.
 __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &M, f3 o, f3 d, float tmax, Lds &lds, Counters &cnt,
                                              float &best_t, uint32_t &best_slot, bool &best_entering) {
-    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    float oe = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) * 9.5367431640625e-7f;
-    f3 op = o + mk3(oe, oe, oe), om = o - mk3(oe, oe, oe);
+    const RaySlabs slabs = make_slabs(M, o, d);
     bool found = false;
     float best = tmax;
     uint32_t best_orig = 0xFFFFFFFFu;
     best_slot = 0;
     best_entering = false;
-    const BvhNode *nodes = S.nodes + M.node_first;
+    const BvhNodeQ *nodes = S.nodes + M.node_first;
     const TriHot *tris = S.tris + M.tri_first;
     const uint32_t *orig = S.tri_index + M.tri_first;
     int sp = 0;
@@ -244,15 +269,12 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
                 cnt.overflow |= 16u;              // RRT_ERR_BIT_INTERNAL
                 break;
             }
-            const BvhNode N = nodes[cur];
+            const BvhNodeQ N = nodes[cur];
             bool hl, hr;
             float nl, nr;
-            box2_test(N, op, om, inv, best, hl, hr, nl, nr);
+            box2_test(N, slabs, best, hl, hr, nl, nr);
             cnt.nodes += 2;
-            int cl = N.child[0], cr = N.child[1];
-            // leaves are encoded as negative ids; pack the leaf count next to it on the stack
-            int el = cl >= 0 ? cl : -(int)(((uint32_t)(~cl) << 4) | N.cnt[0]) - 1;
-            int er = cr >= 0 ? cr : -(int)(((uint32_t)(~cr) << 4) | N.cnt[1]) - 1;
+            const int el = N.child[0], er = N.child[1];  // leaves: negative, first slot and count packed (BvhNodeQ)
             if (hl && hr) {
                 bool left_first = !(nr < nl);
                 lds.st(sp++) = left_first ? er : el;

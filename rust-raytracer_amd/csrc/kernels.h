@@ -62,6 +62,7 @@ struct TraceArgs {
     uint32_t pixel_base;  // first node (band-relative) of this chunk
     uint32_t band_rows;   // rows of the band being rendered (camera renders)
     uint32_t lds_slots;   // hit-list slots per lane (0 = scene has no CSG)
+    uint32_t fuse;        // 1: raytracing mode and level 0 is the whole recursion: k_trace_shade writes the frame itself
     float gather_half_width;
     uint32_t *next_count;
     uint32_t *err;

@@ -94,6 +94,40 @@ __device__ __forceinline__ void level_ray(const TraceArgs &A, uint32_t i, f3 &o,
     }
 }
 
+// level-0 outputs: the frame (any pointer may be null)
+__device__ __forceinline__ void write_pixel(const TraceArgs &A, uint32_t pixel, f3 colour, float depth, uint32_t object) {
+    if (A.out_rgb) {
+        A.out_rgb[(size_t)pixel * 3 + 0] = colour.x;
+        A.out_rgb[(size_t)pixel * 3 + 1] = colour.y;
+        A.out_rgb[(size_t)pixel * 3 + 2] = colour.z;
+    }
+    if (A.out_depth) A.out_depth[pixel] = depth;
+    if (A.out_id) A.out_id[pixel] = object;
+}
+
+// Material part of Scene::raytrace's colour for one node, in the reference's operation order: the fold of the parts'
+// compute_once (`once`), the Global part's Fresnel mix of the children (global_material.rs:100-107) and the compound
+// mean (compound_material.rs:86).  Shared by k_combine and by the fused single-level path of k_trace_shade.
+__device__ __forceinline__ f3 scene_node_total(f3 once, uint32_t flags, float wr, float wt, float div, float kr, bool have_a, f3 ca,
+                                               bool have_b, f3 cb) {
+    f3 total = once;
+    if (flags & NF_HAS_GLOBAL) {
+        f3 gl = mk3(0.0f, 0.0f, 0.0f);
+        if (flags & NF_GLOBAL_ACTIVE) {
+            f3 ra = ca * wr, rb = cb * wt;
+            if (have_a && have_b)
+                gl = (ra * kr) + (rb * (1.0f - kr));
+            else if (have_a)
+                gl = ra;
+            else if (have_b)
+                gl = rb;
+        }
+        total = (div != 0.0f) ? once + gl : gl;
+    }
+    if (div != 0.0f) total = total / div;
+    return total;
+}
+
 #ifndef RRT_MIN_WAVES
 #define RRT_MIN_WAVES 3
 #endif
@@ -127,16 +161,26 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
                 tr.object = 0xFFFFFFFFu;
             }
         }
+        // Fused single-level frames (A.fuse: raytracing mode, no material spawns rays, so level 0 is the whole
+        // recursion): the pixel is finished here with k_combine's arithmetic and nothing goes through the node arrays.
+        const bool fuse = MODE == RRT_MODE_SCENE && A.fuse;
+        const uint32_t out_pixel = fuse ? (A.cam.width ? node_pixel(A.pixel_base + i, A.cam.width, A.band_rows) : A.pixel_base + i) : 0u;
         if (tr.object == 0xFFFFFFFFu) {  // scene.rs:85-90 / photon_scene.rs:311-313
-            A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            A.cur.glob[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
-            A.cur.object_id[i] = 0xFFFFFFFFu;
+            if (fuse) {
+                write_pixel(A, out_pixel, mk3(0.0f, 0.0f, 0.0f), 0.0f, 0xFFFFFFFFu);
+            } else {
+                A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                A.cur.glob[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+                A.cur.object_id[i] = 0xFFFFFFFFu;
+            }
         } else {
             const DevMaterial &M = S.materials[h.material];
             uint32_t flags = NF_HIT;
             float kr = 0.0f;
-            A.cur.object_id[i] = tr.object;
-            A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, tr.t);  // depth = hit.distance (scene.rs:124-127)
+            if (!fuse) {
+                A.cur.object_id[i] = tr.object;
+                A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, tr.t);  // depth = hit.distance (scene.rs:124-127)
+            }
             if (MODE == RRT_MODE_SCENE) {
                 f3 once = material_once_pre(S, M, h, cnt);
                 float wr = 0.0f, wt = 0.0f;
@@ -155,8 +199,14 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
                         if (wt > 0.0f) want_b = global_refraction(G, h, true, d, bo, bd, kr);
                     }
                 }
-                A.cur.once[i] = make_float4(once.x, once.y, once.z, kr);
-                A.cur.glob[i] = make_float4(wr, wt, M.is_compound ? (float)M.n_parts : 0.0f, __uint_as_float(flags));
+                const float div = M.is_compound ? (float)M.n_parts : 0.0f;
+                f3 colour = mk3(0.0f, 0.0f, 0.0f);
+                if (fuse) {
+                    colour = scene_node_total(once, flags, wr, wt, div, kr, false, colour, false, colour);
+                } else {
+                    A.cur.once[i] = make_float4(once.x, once.y, once.z, kr);
+                    A.cur.glob[i] = make_float4(wr, wt, div, __uint_as_float(flags));
+                }
                 // scene.rs:96-122
                 for (uint32_t l = 0; l < S.n_lights; l++) {
                     const DevLight L = S.lights[l];
@@ -171,8 +221,13 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
                     }
                     f3 term = mk3(0.0f, 0.0f, 0.0f);
                     if (lit) term = material_per_light(S, M, h, viewer, ldir, cnt) * light_intensity(L, h.position);
-                    A.cur.lights[(size_t)l * A.cur.capacity + i] = make_float4(term.x, term.y, term.z, lit ? 1.0f : 0.0f);
+                    if (fuse) {
+                        if (lit) colour = colour + term;  // scene.rs:116-121, as k_combine adds them
+                    } else {
+                        A.cur.lights[(size_t)l * A.cur.capacity + i] = make_float4(term.x, term.y, term.z, lit ? 1.0f : 0.0f);
+                    }
                 }
+                if (fuse) write_pixel(A, out_pixel, colour, tr.t, tr.object);
             } else {  // PhotonScene::vueontrace, photon_scene.rs:309-361
                 float sw = M.surface_weight, rw = M.w[3];
                 f3 surface = mk3(0.0f, 0.0f, 0.0f);
@@ -306,7 +361,7 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
             A.next.ray_d[off_b] = make_float4(bd.x, bd.y, bd.z, __uint_as_float(1u));
         }
     }
-    if (active) A.cur.child[i] = child;
+    if (active && !(MODE == RRT_MODE_SCENE && A.fuse)) A.cur.child[i] = child;
 }
 
 // Photon mode: the radiance estimates the trace kernel filed (HeavyRec), one query per wave.  Grid-stride over the
@@ -371,22 +426,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
         }
         if (A.mode == RRT_MODE_SCENE) {
             float wr = g.x, wt = g.y, div = g.z, kr = on.w;
-            f3 total = once;
-            if (flags & NF_HAS_GLOBAL) {
-                f3 gl = mk3(0.0f, 0.0f, 0.0f);
-                if (flags & NF_GLOBAL_ACTIVE) {  // global_material.rs:100-107
-                    bool have_a = ch.x >= 0, have_b = ch.y >= 0;
-                    f3 ra = ca * wr, rb = cb * wt;
-                    if (have_a && have_b)
-                        gl = (ra * kr) + (rb * (1.0f - kr));
-                    else if (have_a)
-                        gl = ra;
-                    else if (have_b)
-                        gl = rb;
-                }
-                total = (div != 0.0f) ? once + gl : gl;
-            }
-            if (div != 0.0f) total = total / div;  // compound_material.rs:86
+            f3 total = scene_node_total(once, flags, wr, wt, div, kr, ch.x >= 0, ca, ch.y >= 0, cb);
             colour = total;
             for (uint32_t l = 0; l < A.S.n_lights; l++) {  // scene.rs:116-121
                 float4 t = A.cur.lights[(size_t)l * A.cur.capacity + i];
@@ -404,13 +444,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
     A.cur.result[i] = make_float4(colour.x, colour.y, colour.z, res.w);
     if (A.level == 0) {
         uint32_t pixel = A.cam.width ? node_pixel(A.pixel_base + i, A.cam.width, A.band_rows) : A.pixel_base + i;
-        if (A.out_rgb) {
-            A.out_rgb[(size_t)pixel * 3 + 0] = colour.x;
-            A.out_rgb[(size_t)pixel * 3 + 1] = colour.y;
-            A.out_rgb[(size_t)pixel * 3 + 2] = colour.z;
-        }
-        if (A.out_depth) A.out_depth[pixel] = res.w;
-        if (A.out_id) A.out_id[pixel] = A.cur.object_id[i];
+        write_pixel(A, pixel, colour, res.w, A.cur.object_id[i]);
     }
 }
 

@@ -79,7 +79,7 @@ struct Flat {
     std::vector<TriHot> tris;
     std::vector<uint32_t> tri_index;
     std::vector<float> tri_normals;
-    std::vector<BvhNode> nodes;
+    std::vector<BvhNodeQ> nodes;
     uint32_t bvh_depth = 0;
     uint64_t flops = 0;
     uint32_t bvh_builder = RRT_BVH_HOST_SAH;
@@ -255,7 +255,9 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
             F.ms_bvh_build += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             F.bvh_depth = std::max(F.bvh_depth, depth);
             mi.node_count = (uint32_t)nodes.size();
-            F.nodes.insert(F.nodes.end(), nodes.begin(), nodes.end());
+            std::vector<BvhNodeQ> qnodes;
+            quantise_bvh(nodes, mi, qnodes);
+            F.nodes.insert(F.nodes.end(), qnodes.begin(), qnodes.end());
             F.tris.reserve(F.tris.size() + n);
             F.tri_index.reserve(F.tri_index.size() + n);
             for (uint32_t k = 0; k < n; k++) {
@@ -416,7 +418,7 @@ int flatten_scene(rrt_scene *s) {
             put(F.tris.data(), sizeof(TriHot), F.tris.size());
             put(F.tri_index.data(), 4, F.tri_index.size());
             put(F.tri_normals.data(), 4, F.tri_normals.size());
-            put(F.nodes.data(), sizeof(BvhNode), F.nodes.size());
+            put(F.nodes.data(), sizeof(BvhNodeQ), F.nodes.size());
             fclose(f);
         }
     }
@@ -601,6 +603,7 @@ void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, ui
     A.pixel_base = base;
     A.band_rows = cam && cam->width ? n_pixels / cam->width : 0;
     A.lds_slots = D.lds_slots;
+    A.fuse = (s->mode == RRT_MODE_SCENE && !D.reflective) ? 1u : 0u;  // single-level frames need no combine pass
     A.gather_half_width = s->params.gather_half_width;
     A.err = L.ctr + 63;
     A.stats = s->stats_dev.p;
@@ -625,7 +628,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     int rc;
     uint32_t want_lanes = s->params.render_streams ? std::min(s->params.render_streams, 8u) : 1u;
     if (n_levels == 1) want_lanes = 1;  // no deep levels to hide
-    uint32_t chunk = s->params.chunk_pixels ? s->params.chunk_pixels : (1u << 22);
+    uint32_t chunk = s->params.chunk_pixels ? s->params.chunk_pixels : (1u << 23);  // a 3840x2160 frame is one chunk
     if (want_lanes > 1 && n_pixels >= (1u << 18)) {  // big enough to be worth cutting: one chunk per lane, whole waves
         uint32_t per_lane = (n_pixels + want_lanes - 1) / want_lanes;
         per_lane = (per_lane + 255u) & ~255u;
@@ -668,7 +671,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
             plan.push_back(c);
             round_base += c.n;
         }
-        bool predicted = allow_predicted && n_levels > 1;
+        bool predicted = allow_predicted;  // single-level frames too: no readback between launches, one sync per round
         for (size_t j = 0; j < plan.size(); j++) {
             const auto &all = s->lanes[j]->prediction;
             const std::vector<uint32_t> &pred = round < all.size() ? all[round] : no_prediction;
@@ -723,7 +726,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     launch_gather_heavy(A, st);
                 }
                 RRT_HIP(hipEventRecord(L.ev_trace1, st));
-                for (int k = (int)n_run - 1; k >= 0; k--) {
+                for (int k = (int)n_run - 1; k >= 0 && !A.fuse; k--) {
                     A.cur = L.levels[k].view();
                     A.next = L.levels[k + 1].view();
                     A.count = caps[k];
@@ -815,7 +818,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     secondary += next_n;
                     if (next_n == 0) break;
                 }
-                for (int k = (int)last; k >= 0; k--) {
+                for (int k = (int)last; k >= 0 && !A.fuse; k--) {
                     A.cur = L.levels[k].view();
                     A.next = L.levels[k + 1].view();
                     A.count = counts[k];
@@ -828,7 +831,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                 err |= L.host_pinned[0];
             }
         }
-        if (n_levels > 1)  // what the next frame's chunks of these sizes will be launched for
+        // what the next frame's chunks of these sizes will be launched for
             for (size_t j = 0; j < plan.size(); j++) {
                 if (s->lanes[j]->prediction.size() <= round) s->lanes[j]->prediction.resize(round + 1);
                 std::vector<uint32_t> &pred = s->lanes[j]->prediction[round];

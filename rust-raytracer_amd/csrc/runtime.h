@@ -64,7 +64,7 @@ struct DeviceScene {
     DBuf<TriHot> tris;
     DBuf<uint32_t> tri_index;
     DBuf<float> tri_normals;
-    DBuf<BvhNode> nodes;
+    DBuf<BvhNodeQ> nodes;
     DBuf<DevMaterial> materials;
     DBuf<DevTexture> textures;
     DBuf<uchar4> texels8;
@@ -183,6 +183,8 @@ int read_stats(rrt_scene *s, unsigned long long out[ST_COUNT]);
 int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
                 const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream);
 void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth);
+// bvh_build.cpp: the traversal's 32-byte nodes from either builder's output; fills the mesh's grid (qbase, qscale, qmag, wild)
+void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<BvhNodeQ> &out);
 // bvh_lbvh.hip: the same outputs from the device-side LBVH build (n > 4); device_ms = HIP-event time of its kernels
 int build_bvh_device(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
                      float *device_ms);

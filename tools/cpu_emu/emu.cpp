@@ -106,7 +106,7 @@ int main(int argc, char **argv) {
     auto tris = get<TriHot>(f);
     auto tri_index = get<uint32_t>(f);
     auto tri_normals = get<float>(f);
-    auto nodes = get<BvhNode>(f);
+    auto nodes = get<BvhNodeQ>(f);
     fclose(f);
     DevScene S;
     memset(&S, 0, sizeof(S));
