@@ -260,12 +260,13 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
     const BvhNodeQ *nodes = S.nodes + M.node_first;
     const TriHot *tris = S.tris + M.tri_first;
     const uint32_t *orig = S.tri_index + M.tri_first;
+    const uint32_t node_count = M.node_count, tri_count = M.tri_count;  // locals: M is memory the loop would re-read
     int sp = 0;
     int cur = 0;  // root
-    if (M.tri_count == 0) return false;
+    if (tri_count == 0) return false;
     for (;;) {
         if (cur >= 0) {
-            if ((uint32_t)cur >= M.node_count) {  // index guard: refuse a wild node id instead of faulting the GPU
+            if ((uint32_t)cur >= node_count) {  // index guard: refuse a wild node id instead of faulting the GPU
                 cnt.overflow |= 16u;              // RRT_ERR_BIT_INTERNAL
                 break;
             }
@@ -290,7 +291,7 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
         } else {
             uint32_t code = (uint32_t)(-(cur + 1));
             uint32_t first = code >> 4, n = code & 15u;
-            if (first + n > M.tri_count) {  // index guard, as above
+            if (first + n > tri_count) {  // index guard, as above
                 cnt.overflow |= 16u;
                 break;
             }
