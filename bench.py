@@ -1,39 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the render hot path on MI355X.
 
-Workload at N=1 (BASELINE.json configs[1]): the quadric + CSG + Fresnel scene
-`assets/scenes/c2_quadric_csg_fresnel.txt` at 1920x1080.  One "step" = one full frame through
-the wavefront pipeline (primary rays, up to 5 levels of reflection/refraction rays, shadow rays),
-scene resident in HBM, outputs written to HBM.  Metric: Mrays/s = (primary + secondary + shadow
-rays traced) / wall time.  With N ranks every rank renders its own frame of a camera orbit per step
-(frames are independent objects: no data-path collective), so scaling is "weak".
+Workload (every N): BASELINE.json configs[3], the configuration north_star's target is quoted on — a 1 M-triangle mesh
+(13 x 13 grid of assets/models/teapot.obj, 1,068,080 triangles, BVH in HBM) on a floor, one point light, 3840 x 2160.
+One "step" = ONE frame: primary rays through the BVH, shadow rays, shading, frame written to HBM on rank 0.  Metric:
+Mrays/s = (primary + secondary + shadow rays traced) / wall time, frames rendered one after the other.
 
-Frames in flight.  The deep recursion levels of a frame hold few rays: their launches cost one wave's latency each and
-leave most of the GPU idle, and every frame ends with a host round trip for its counters.  Independent frames fill
-those gaps, so a rank drives `--frames-in-flight` (default 3: with torch's own stream that makes the 4 hardware queues a
-process has on this pool) frame pipelines -- a host thread and a HIP stream each, all rendering on ONE scene handle
-(concurrent render calls on a handle are part of the C ABI, as `raytrace(&self)` is in the reference), exactly what a
-host application rendering a camera path would do with this library -- and the K timed steps are dealt round-robin to
-them.  `config.value_one_frame_in_flight` is the same measurement with one pipeline.
+N ranks render ONE frame together (north_star: "image tiles shard over GPUs"): its rows are dealt round-robin in groups
+of 8 (rrt_render_interleaved_device: contiguous bands would leave the ranks with the sky idle), every rank renders its
+share into one packed buffer, and ONE RCCL gather per frame brings the shares to rank 0, which puts the rows back in
+image order.  Total work is fixed as N grows: "scaling": "strong".  The gather of frame f overlaps the rendering of
+frame f + 1 (two buffers); `collective_ms` is the time rank 0 spends waiting for gathers per step and
+`collective_gb_per_s` the bytes it received per step over that time.  At N = 1 there is no collective and the frame is
+rendered straight into the frame buffers: the N = 1 value IS the single-GPU number.
 
-Extra legs (same JSON line):
-  `cpu_baseline`  the CPU oracle (a port of the reference's brute-force algorithm; the Rust binary cannot be
-                  built here: no Rust toolchain) rendering whole frames of the same workload for >= 12 s on
-                  min(16, cpus) threads, row bands like camera.rs:14-42.
-  `roofline`      k_trace_shade, the kernel that holds ~88 % of the GPU time.  It is neither HBM- nor MFMA-bound:
-                  ray/primitive intersection is divergent scalar-per-lane FP32 work with IEEE division and
-                  square roots that may not be contracted into FMAs (bit-exact parity), so the ceiling that
-                  applies is the vector FP32 rate ("valu_fp32", 157.3 TFLOP/s, which counts an FMA as two).
-                  achieved = algorithmic flops (per-primitive flops of the reference's brute
-                  force loop x rays traced, + 27 per ray/box and 61 per ray/triangle test) / HIP-event time of
-                  the launches on their stream (rrt_stats.ms_trace_kernels), taken in a pass of its own that
-                  renders the same frames one at a time (overlapping launches share the GPU, so their durations
-                  would not add up to GPU time).  `traffic` = HBM bytes per launch
-                  from the committed PMC passes (profiles/r01_final/pmc_traffic.json, FETCH_SIZE doubled as
-                  the MI355X guide prescribes for 16-B-per-lane reads); `hbm_frac` prices the same launches
-                  against 8 TB/s to show how far from the HBM roof the kernel is.
-  `extra`         the other two single-GPU configs of BASELINE.json (1M-triangle mesh at 4K, 1M photons),
-                  short runs (bench_extra.py).
+The same JSON line carries
+  `roofline`      k_trace_shade (the traversal + shading kernel, > 95 % of the GPU time of a frame).  It is neither HBM-
+                  nor MFMA-bound: BVH traversal and the reference's triangle test are divergent per-lane FP32 work whose
+                  parity-relevant part may not be contracted into FMAs, so the roof is the vector FP32 rate
+                  ("valu_fp32").  `achieved` = algorithmic flops (27 per ray/box and 61 per ray/triangle
+                  test the traversal performed + the analytic primitives of every trace) / HIP-event time of the launches
+                  on their stream; `peak` 157.3 TFLOP/s counts an FMA as two and packed issue, `frac_no_fma` prices the
+                  same work against the 39.3 TFLOP/s that plain one-flop-per-lane instructions can reach; `traffic` = HBM
+                  bytes per launch from the committed PMC passes (profiles/r02/).
+  `cpu_baseline`  the CPU oracle (a port of the reference's brute-force loop over every triangle; the Rust binary cannot
+                  be built here) on a bounded sample of the same frame's camera rays, min(16, cpus) threads.
+  `extra`         N = 1: the other single-GPU configurations (configs[1] CSG scene, configs[2] photon-mapped scene2,
+                  configs[3] with reflective / refractive teapots).  N > 1: `photon_pass`, north_star's second split —
+                  photon emission by index range, the RCCL all-gather of the photon maps (bytes, GB/s against the
+                  153 GB/s of one xGMI link), per-rank index build, interleaved render + gather (configs[4] scaled:
+                  12.5 M photons per rank).
 """
 import argparse
 import importlib
@@ -41,6 +37,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -48,70 +45,99 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 (packed FMA), MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP32_NO_FMA = 39.325  # the same lanes issuing one plain (unpacked, unfused) flop per cycle
 PEAK_HBM_GBS = 8000.0
+XGMI_LINK_GBS = 153.0
 
 
-def orbit_camera(rrt, base, rank, step):
-    """Frame `step` of rank `rank`: the C2 camera moved along x (keeps lookat/up perpendicular)."""
-    import ctypes as C
-
-    cam = type(base)()
-    C.memmove(C.byref(cam), C.byref(base), C.sizeof(base))
-    if rank or step:
-        cam.position[0] = base.position[0] + 0.15 * rank + 0.01 * (step % 8)
-    return cam
-
-
-def cpu_baseline(scene_path, cam, min_seconds=12.0):
-    """Oracle (CPU port of the reference's brute-force algorithm, threaded by row bands like camera.rs:14-42) on
-    whole frames of the same workload until at least `min_seconds` of wall time have passed."""
+def cpu_baseline_mesh(rrt, cam, rays_wanted=2304):
+    """The oracle's brute force (every ray against every triangle, polymesh_object.rs:216-242) on camera rays spread evenly
+    over the same frame, traced from min(16, cpus) host threads."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
+    import bench_extra
     import oracle_binding as ob
 
-    so, _ = ob.OracleScene.load(scene_path)
+    so = ob.OracleScene()
+    bench_extra.build_mesh_scene(rrt, scene=so)
+    so.pre_render(1, threads=1)
+    step = max(1, int(math.sqrt(cam.width * cam.height / rays_wanted)))
+    xs, ys = np.arange(step // 2, cam.width, step), np.arange(step // 2, cam.height, step)
+    rays = [rrt.camera_ray(cam, int(x), int(y)) for y in ys for x in xs]
+    o = np.ascontiguousarray([r[0] for r in rays], np.float32)
+    d = np.ascontiguousarray([r[1] for r in rays], np.float32)
     cores = min(16, os.cpu_count() or 1)
-    frames = 0
+    before = so.stats()
     t0 = time.perf_counter()
-    while True:
-        so.render(cam, threads=cores)
-        frames += 1
-        dt = time.perf_counter() - t0
-        if dt >= min_seconds or frames >= 200:
-            break
-    st = so.stats()
-    rays = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+    parts = np.array_split(np.arange(len(o)), cores)
+    th = [threading.Thread(target=lambda idx=idx: so.raytrace(o[idx], d[idx])) for idx in parts if len(idx)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    after = so.stats()
+    traced = sum(after[k] - before[k] for k in ("rays_primary", "rays_secondary", "rays_shadow"))
     return {
-        "value": rays / dt / 1e6,
-        "unit": "Mrays/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": "%d whole 1920x1080 frames of the same scene on %d threads (%d rays, %.1f s)" % (frames, cores, rays, dt),
+        "value": traced / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": "%d camera rays of the same 3840x2160 frame (every %dth pixel in x and y) + their shadow rays = %d rays, brute force over "
+                  "1068080 triangles on %d threads, %.1f s" % (len(o), step, traced, cores, dt),
     }
 
 
-def measured_traffic(scene_path, width, height):
-    """HBM bytes per k_trace_shade launch from the committed PMC passes; only valid for the workload they were taken on."""
-    f = os.path.join(REPO, "profiles/r01_final/pmc_traffic.json")
-    if not (os.path.exists(f) and scene_path.endswith("c2_quadric_csg_fresnel.txt") and (width, height) == (1920, 1080)):
+def measured_traffic():
+    """HBM bytes per k_trace_shade launch of this workload from the committed PMC passes."""
+    f = os.path.join(REPO, "profiles/r02/c4_mesh_pmc_traffic.json")
+    if not os.path.exists(f):
         return None
     with open(f) as fh:
         return json.load(fh).get("hbm_bytes_per_launch")
 
 
+def photon_pass_leg(rrt, torch, D, dist, rank, world, device, stage_host, photons_per_rank, width, height, interleave):
+    """north_star's second split, timed phase by phase: photon emission by index range, the all-gather of the photon maps,
+    the index build every rank does for itself, the interleaved render and its gather."""
+    abi = rrt._abi
+    photons, caustic = photons_per_rank * world, max(1000, photons_per_rank // 500) * world
+    params = rrt.default_params(photons_per_light=photons, caustic_photons_per_light=caustic)
+    scene, cam = rrt.Scene.load(os.path.join(REPO, "assets/scenes/scene2.txt"), params=params, mode_override=abi.MODE_PHOTON)
+    cam.width, cam.height = width, height
+    ex = D.StagedPhotonExchange(scene, "cuda") if stage_host else D.DevicePhotonExchange(scene, "cuda")
+    info = None
+    for seed in (1, 2):  # the first pass sizes buffers and warms RCCL up; the second is reported
+        info = D.photon_pass(scene, ex, 1, photons, caustic, seed, rank, world, dist, "cpu" if stage_host else device)
+    fg = D.FrameGather(rrt, cam, rank, world, dist, device, interleave=interleave, stage_host=stage_host)
+    stream = torch.cuda.current_stream().cuda_stream
+    times = {}
+    for it in range(2):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        fg.render(scene, cam, 0, stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fg.start_gather(0)
+        fg.finish(0)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        times = {"render_share": (t1 - t0) * 1e3, "gather_frame": (t2 - t1) * 1e3}
+    st = scene.stats()
+    n_records = scene.photon_count(0) + scene.photon_count(1)
+    out = {"ms": dict(info["ms"], **times), "bytes": info["bytes"], "records": n_records, "gathered_this_rank": st["photons_gathered"]}
+    return out, photons + caustic
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
-                    help="independent frame pipelines per rank (scene handle + host thread + HIP stream each); the steps "
-                         "are dealt round-robin to them.  1 = every frame finishes before the next one starts")
-    ap.add_argument("--streams", type=int, default=0, help="rrt_params.render_streams (0 = library default)")
-    ap.add_argument("--static-camera", action="store_true", help="render the same frame every step")
-    ap.add_argument("--scene", default=os.path.join(REPO, "assets/scenes/c2_quadric_csg_fresnel.txt"))
+    ap.add_argument("--interleave", type=int, default=8, help="rows per group dealt round-robin to the ranks (0 = contiguous bands, camera.rs:14-31)")
+    ap.add_argument("--variant", default="phong", help="mesh scene variant: phong (configs[3]), mirror, glass")
+    ap.add_argument("--photons-per-rank", type=int, default=12_500_000, help="N > 1 extra leg: photons emitted per rank (configs[4]: 100 M over 8)")
     args = ap.parse_args()
 
     import torch
@@ -121,11 +147,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: librrt has no CPU fallback")
-    # RRT_BENCH_REHEARSAL=1: run the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, gloo instead
-    # of RCCL, which refuses two ranks on one device).  For checking the launch / sharding / reduction plumbing only.
+    # RRT_BENCH_REHEARSAL=1: run the N > 1 path on a box with fewer GPUs than ranks (ranks share devices; gloo with host
+    # staging instead of RCCL, which refuses two ranks on one device).  Checks the sharding / collective plumbing only.
     rehearsal = os.environ.get("RRT_BENCH_REHEARSAL") == "1"
     device_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -133,144 +160,93 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-    reduce_device = "cpu" if rehearsal else "cuda"
+            dist.init_process_group("nccl", device_id=device)
+    reduce_device = "cpu" if rehearsal else device
 
     rrt = importlib.import_module("rust-raytracer_amd")
-    F = max(1, args.frames_in_flight)
+    D = importlib.import_module("rust-raytracer_amd.distributed")
+    import bench_extra
 
-    shared_scene, shared_cam = rrt.Scene.load(args.scene, params=rrt.default_params(render_streams=args.streams))
-    shared_scene.pre_render(seed=1)
-
-    class Worker:
-        """One frame pipeline: a host thread with its own output buffers and HIP stream, rendering on the SHARED scene
-        handle (concurrent render calls on one handle each get their own queues inside the library; the flattened scene
-        is in HBM once).  rrt_get_stats returns the calling thread's own last frame."""
-
-        def __init__(self, k):
-            self.k = k
-            self.scene, self.cam0 = shared_scene, shared_cam
-            W, H = self.cam0.width, self.cam0.height
-            self.rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-            self.depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
-            self.ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
-            self.stream = torch.cuda.Stream() if F > 1 else torch.cuda.current_stream()
-            self.reset()
-
-        def reset(self):
-            self.rays = self.flops = self.repeated = 0
-            self.kernel_ms = 0.0
-            self.frames = 0
-            self.error = None
-
-        def step(self, i):
-            cam = self.cam0 if args.static_camera else orbit_camera(rrt, self.cam0, rank, i)
-            self.scene.render_device(cam, 0, cam.height, self.rgb.data_ptr(), self.depth.data_ptr(), self.ids.data_ptr(), self.stream.cuda_stream)
-            st = self.scene.stats()
-            self.rays += st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
-            self.kernel_ms += st["ms_trace_kernels"]
-            self.flops += st["flops_algorithmic"]
-            self.repeated = st["frames_repeated"]
-            self.frames += 1
-
-        def run(self, first, count, stride):  # frames first, first + stride, ... < count
-            try:
-                torch.cuda.set_device(device_index)  # HIP's current device is per thread; new threads start on device 0
-                for i in range(first, count, stride):
-                    self.step(i)
-            except Exception as e:  # surfaces in the main thread
-                self.error = e
-
-    workers = [Worker(k) for k in range(F)]
-    cam0 = workers[0].cam0
-    W, H = cam0.width, cam0.height
+    scene, cam, ntri = bench_extra.build_mesh_scene(rrt, variant=args.variant)
+    t0 = time.perf_counter()
+    scene.pre_render(seed=1)
+    t_pre = time.perf_counter() - t0
+    fg = D.FrameGather(rrt, cam, rank, world, dist, device, interleave=args.interleave, stage_host=rehearsal)
+    stream = torch.cuda.current_stream().cuda_stream
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The pipelines' host threads live for the whole run and wait at a barrier between phases: starting threads inside
-    # the timed region would cost about a frame's time each.
-    import threading
+    acc = {"rays": 0, "kernel_ms": 0.0, "flops": 0, "wait_ms": 0.0, "st": None}
 
-    phase = {"n": 0, "stop": False}
-    gate_in, gate_out = threading.Barrier(F + 1), threading.Barrier(F + 1)
+    def run_steps(n):
+        """n frames, one after the other; the gather of a frame is in flight while the next one renders."""
+        for i in range(n):
+            k = i % 2
+            if i >= 2:
+                t = time.perf_counter()
+                fg.finish(k)  # buffer k is about to be rendered into again: its gather (frame i - 2) must be done
+                acc["wait_ms"] += (time.perf_counter() - t) * 1e3
+            fg.render(scene, cam, k, stream)
+            st = scene.stats()
+            acc["rays"] += st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+            acc["kernel_ms"] += st["ms_trace_kernels"]
+            acc["flops"] += st["flops_algorithmic"]
+            acc["st"] = st
+            fg.start_gather(k)
+        t = time.perf_counter()
+        for i in range(max(0, n - 2), n):
+            fg.finish(i % 2)
+        acc["wait_ms"] += (time.perf_counter() - t) * 1e3
 
-    def pipeline_thread(j):
-        torch.cuda.set_device(device_index)
-        while True:
-            gate_in.wait()
-            if phase["stop"]:
-                return
-            workers[j].run(j, phase["n"], F)
-            gate_out.wait()
-
-    threads = [threading.Thread(target=pipeline_thread, args=(j,), daemon=True) for j in range(F)] if F > 1 else []
-    for t in threads:
-        t.start()
-
-    def run_steps(n, active):
-        """n steps (frames 0 .. n-1), dealt round-robin to the pipelines (all of them, or pipeline 0 alone)."""
-        if len(active) == 1:
-            active[0].run(0, n, 1)
-        else:
-            phase["n"] = n
-            gate_in.wait()
-            gate_out.wait()
-        for w in active:
-            if w.error is not None:
-                raise w.error
-
-    # set-up, not warm-up: every pipeline renders one frame on its OWN thread (queue sizes, and whatever HIP sets up the
-    # first time a thread launches)
-    run_steps(F, workers)
-    run_steps(args.warmup, workers)
-    for w in workers:
-        w.reset()
+    run_steps(2)  # set-up: queues sized, both buffers used once
+    run_steps(args.warmup)
+    for k in ("rays", "flops"):
+        acc[k] = 0
+    acc["kernel_ms"] = acc["wait_ms"] = 0.0
+    repeated_before = scene.stats()["frames_repeated"]
     sync()
     t0 = time.perf_counter()
-    run_steps(args.steps, workers)
+    run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
-    rays = sum(w.rays for w in workers)
-    repeated = sum(w.repeated for w in workers)
-    st_frames = sum(w.frames for w in workers)
-    assert st_frames == args.steps, (st_frames, args.steps)
+    repeated = scene.stats()["frames_repeated"] - repeated_before
+    rays, kernel_ms, flops, wait_ms, st = acc["rays"], acc["kernel_ms"], acc["flops"], acc["wait_ms"], acc["st"]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=reduce_device)
+        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        r = torch.tensor([rays], dtype=torch.float64, device=reduce_device)
+        dt, kernel_ms_max = float(t[0].item()), float(t[1].item())
+        r = torch.tensor([rays, flops], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        total_rays = float(r.item())
+        total_rays, total_flops = float(r[0].item()), float(r[1].item())
     else:
-        total_rays = float(rays)
+        total_rays, total_flops, kernel_ms_max = float(rays), float(flops), kernel_ms
 
-    # Roofline pass: the same frames ONE AT A TIME on pipeline 0.  Per-launch HIP-event durations only add up to GPU time
-    # when launches of different frames do not overlap; with several frames in flight each launch shares the GPU with
-    # the neighbours' launches and its duration says nothing about the kernel.
-    w0 = workers[0]
-    w0.reset()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    w0.run(0, min(args.steps, 40), 1)
-    torch.cuda.synchronize()
-    dt_one = time.perf_counter() - t1
-    if w0.error is not None:
-        raise w0.error
-    kernel_ms, flops, one_frames, one_rays = w0.kernel_ms, w0.flops, w0.frames, w0.rays
-    if threads:
-        phase["stop"] = True
-        gate_in.wait()
-        for t in threads:
-            t.join()
+    extra = {}
+    if world > 1 and not args.no_extra:
+        try:
+            leg, emitted = photon_pass_leg(rrt, torch, D, dist, rank, world, device, rehearsal, args.photons_per_rank, cam.width, cam.height, args.interleave)
+            ms, by = leg["ms"], leg["bytes"]
+            ag = ms.get("allgather_maps", 0.0)
+            leg.update({
+                "workload": "configs[4] scaled: scene2 photon mode, %d photons per rank (%d emitted in all), %dx%d, %d ranks" % (args.photons_per_rank, emitted, cam.width, cam.height, world),
+                "mphotons_per_s_emitted": emitted / (ms["shoot"] * 1e-3) / 1e6 if ms.get("shoot") else None,
+                "collective_ms": ag, "collective_bytes": by.get("allgather_maps", 0),
+                "collective_gb_per_s": by.get("allgather_maps", 0) / (ag * 1e-3) / 1e9 if ag else None,
+                "xgmi_link_gb_per_s": XGMI_LINK_GBS,
+            })
+            extra["photon_pass"] = leg
+        except Exception as e:  # extra legs must never hide the headline number
+            extra["photon_pass"] = {"error": repr(e)}
 
     if rank == 0:
+        # this rank's launches (its share of every frame): flops of the share / HIP-event time of the share's launches
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        traffic = measured_traffic(args.scene, W, H)
-        launches = 6  # recursion levels 0..5 of a frame
-        hbm_gbs = traffic * launches / (kernel_ms / max(1, one_frames) * 1e-3) / 1e9 if traffic and kernel_ms > 0 else None
+        traffic = measured_traffic() if world == 1 else None
+        per_launch_ms = kernel_ms / max(1, args.steps)
+        gather_bytes = fg.bytes_per_frame()
         out = {
             "metric": "Mrays/s (primary+secondary+shadow rays traced)",
             "value": total_rays / dt / 1e6,
@@ -280,47 +256,55 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "collective_ms": wait_ms / args.steps if world > 1 else 0.0,
+            "collective_gb_per_s": (gather_bytes * args.steps / (wait_ms * 1e-3) / 1e9) if world > 1 and wait_ms > 0 else None,
             "config": {
-                "workload": "BASELINE configs[1]: quadric + CSG + Fresnel scene, 1920x1080, one frame per rank per step",
-                "frames_in_flight": F,
-                "value_one_frame_in_flight": one_rays / dt_one / 1e6,
-                "scene": os.path.relpath(args.scene, REPO),
-                "rays_per_frame": rays // max(1, args.steps),
-                "parallelism": "frames sharded over %d rank(s), no collective" % world + (" (REHEARSAL: ranks share devices)" if rehearsal else ""),
+                "workload": "BASELINE configs[3]: %d-triangle mesh (13x13 grid of assets/models/teapot.obj) + floor, 1 point light, 3840x2160, "
+                            "%s; one frame per step, frames one at a time" % (ntri, args.variant),
+                "rays_per_frame": int(total_rays // max(1, args.steps)),
+                "parallelism": ("one GPU" if world == 1 else "rows of each frame dealt to %d ranks in groups of %d, one gather per frame to rank 0 (%d bytes), "
+                                "overlapped with the next frame" % (world, args.interleave, gather_bytes)) + (" (REHEARSAL: ranks share devices, gloo + host staging)" if rehearsal else ""),
                 "frames_repeated": repeated,
+                "bvh_box_tests_per_ray": st["bvh_nodes_visited"] / max(1, st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]),
+                "bvh_tris_per_ray": st["bvh_tris_tested"] / max(1, st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]),
+                "pre_render_s": t_pre, "ms_bvh_build": st["ms_bvh_build"],
             },
             "roofline": {
-                "kernel": "k_trace_shade (all recursion levels of a frame)",
+                "kernel": "k_trace_shade<0, 2> (traversal + shading; one launch per frame)",
                 "bound": "valu_fp32",
                 "achieved": achieved,
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
+                "peak_no_fma": PEAK_FP32_NO_FMA,
+                "frac_no_fma": achieved / PEAK_FP32_NO_FMA,
                 "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_final/pmc_traffic.json)",
-                "hbm_gb_per_s": hbm_gbs,
-                "hbm_frac": hbm_gbs / PEAK_HBM_GBS if hbm_gbs else None,
-                "launches_per_frame": launches,
-                "kernel_ms_per_frame": kernel_ms / max(1, one_frames),
-                "algorithmic_flops_per_frame": flops // max(1, one_frames),
-                "pass": "%d of the same frames, one at a time on one pipeline, right after the timed region" % one_frames,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, corrected as the MI355X guide prescribes; profiles/r02/c4_mesh_pmc_traffic.json)",
+                "hbm_gb_per_s": traffic / (per_launch_ms * 1e-3) / 1e9 if traffic and per_launch_ms > 0 else None,
+                "hbm_frac": traffic / (per_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if traffic and per_launch_ms > 0 else None,
+                "kernel_ms_per_launch": per_launch_ms,
+                "algorithmic_flops_per_launch": int(flops // max(1, args.steps)),
+                "pass": "the timed region itself: frames run one at a time, so HIP-event durations add up to GPU time",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.scene, cam0)
+            out["cpu_baseline"] = cpu_baseline_mesh(rrt, cam)
         if world == 1 and not args.no_extra:
             try:
-                import bench_extra
-
-                out["extra"] = bench_extra.run(rrt, torch)
-            except Exception as e:  # extra legs must never hide the headline number
-                out["extra"] = {"error": repr(e)}
+                extra.update(bench_extra.run(rrt, torch))
+                ms3 = bench_extra.frames_in_flight_ms(torch, scene, cam, 30)
+                out["config"]["value_3_frames_in_flight"] = (total_rays / args.steps) / (ms3 * 1e-3) / 1e6
+            except Exception as e:
+                extra["error"] = repr(e)
+        if extra:
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,8 +1,10 @@
-"""Extra single-GPU legs of bench.py: the other two one-GPU configurations of BASELINE.json.
+"""The workloads of bench.py and its extra single-GPU legs.
 
-mesh    configs[3]: a 1 M-triangle mesh (13 x 13 grid of assets/models/teapot.obj = 1,068,080 triangles,
-        generated here deterministically — the reference ships no mesh of that size) at 3840 x 2160,
-        Monochrome material, one point light: BVH traversal for primary and shadow rays.
+mesh    configs[3] (bench.py's headline): a 1 M-triangle mesh (13 x 13 grid of assets/models/teapot.obj = 1,068,080
+        triangles, generated here deterministically — the reference ships no mesh of that size) at 3840 x 2160,
+        Monochrome material, one point light: BVH traversal for primary and shadow rays.  Variants "mirror" and "glass"
+        give the teapots reflective / refractive compound materials, so that incoherent secondary rays walk the BVH.
+csg     configs[1]: the quadric + CSG + Fresnel scene at 1920 x 1080 (round 1's headline), one and three frames in flight.
 photon  configs[2]: assets/scenes/scene2.txt in photon mode, 1 M photons + 10 k caustic, seed 1, 1024^2:
         emission/bounce pass, index build, gather render.
 """
@@ -52,14 +54,15 @@ def teapot_grid(nx=13, nz=13, spacing=34.0):
     return np.ascontiguousarray(np.concatenate(P), np.float32), np.ascontiguousarray(np.concatenate(N), np.float32)
 
 
-def build_mesh_scene(rrt, smooth=True, bvh_builder=0, variant="phong"):
+def build_mesh_scene(rrt, smooth=True, bvh_builder=0, variant="phong", scene=None):
     """variant: "phong" (BASELINE configs[3]: Monochrome teapots, primary + shadow rays), "nolight" (the same without the
     light: primary rays only), "mirror" (teapots `Simple` = Compound[Monochrome, Global(reflect 0.6)], floor mirror too:
     reflection rays bounce between the teapots and the floor, compound_material.rs:39-49) and "glass" (`Transparent`,
     ior 1.5: reflection + refraction rays, compound_material.rs:51-63): secondary rays that walk the BVH incoherently."""
     abi = rrt._abi
     pos, nrm = teapot_grid()
-    s = rrt.Scene(params=rrt.default_params(bvh_builder=bvh_builder))
+    # `scene`: any object with the construction verbs of rrt.Scene (the CPU oracle's scene for bench.py's cpu_baseline leg)
+    s = scene if scene is not None else rrt.Scene(params=rrt.default_params(bvh_builder=bvh_builder))
 
     def mono(colour, ambient, shininess):
         m = abi.MaterialDesc()
@@ -245,9 +248,66 @@ def run_photon(rrt, torch, photons=1_000_000, steps=3):
     }
 
 
+def render_loop(torch, scene, cam, steps, warmup=2):
+    """`steps` frames one after the other on the current stream: (ms per frame, stats of the last frame, kernel ms, flops, rays)."""
+    W, H = cam.width, cam.height
+    rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), stream)
+    torch.cuda.synchronize()
+    rays = flops = 0
+    kernel_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        scene.render_device(cam, 0, H, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), stream)
+        st = scene.stats()
+        rays += st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+        kernel_ms += st["ms_trace_kernels"]
+        flops += st["flops_algorithmic"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt / steps * 1e3, st, kernel_ms / steps, flops // steps, rays // steps
+
+
+def run_mesh_variant(rrt, torch, variant, steps=5):
+    """configs[3] with secondary rays: the whole recursion (up to 5 bounces) over the 1 M-triangle BVH."""
+    scene, cam, ntri = build_mesh_scene(rrt, variant=variant)
+    scene.pre_render(1)
+    ms, st, kernel_ms, flops, rays = render_loop(torch, scene, cam, steps)
+    traced = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
+    return {
+        "workload": "configs[3] with %s teapots (reflection%s rays through the BVH), %d triangles, 3840x2160" % (variant, " + refraction" if variant == "glass" else "", ntri),
+        "value": rays / ms / 1e3, "unit": "Mrays/s", "ms_per_frame": ms, "kernel_ms_per_frame": kernel_ms,
+        "rays_per_frame": rays, "rays_secondary": st["rays_secondary"], "rays_shadow": st["rays_shadow"],
+        "bvh_box_tests_per_ray": st["bvh_nodes_visited"] / traced, "bvh_tris_per_ray": st["bvh_tris_tested"] / traced,
+    }
+
+
+def run_csg(rrt, torch, steps=60):
+    """configs[1]: round 1's headline, one frame at a time and three in flight."""
+    scene, cam = rrt.Scene.load(os.path.join(REPO, "assets/scenes/c2_quadric_csg_fresnel.txt"))
+    scene.pre_render(1)
+    ms, st, kernel_ms, flops, rays = render_loop(torch, scene, cam, steps, warmup=3)
+    ms_3 = frames_in_flight_ms(torch, scene, cam, steps)
+    achieved = flops / (kernel_ms * 1e-3) / 1e12
+    return {
+        "workload": "BASELINE configs[1]: quadric + CSG + Fresnel scene, 1920x1080",
+        "value": rays / ms / 1e3, "unit": "Mrays/s", "ms_per_frame": ms,
+        "value_3_frames_in_flight": rays / ms_3 / 1e3, "ms_per_frame_3_frames_in_flight": ms_3,
+        "rays_per_frame": rays, "rays_secondary": st["rays_secondary"], "rays_shadow": st["rays_shadow"],
+        "roofline": {"kernel": "k_trace_shade (six recursion levels of a frame)", "bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "kernel_ms_per_frame": kernel_ms, "algorithmic_flops_per_frame": flops},
+    }
+
+
 def run(rrt, torch):
     out = {}
-    for name, fn in (("mesh_1m", run_mesh), ("photon_1m", run_photon)):
+    legs = (("csg_1080p", run_csg), ("photon_1m", run_photon), ("mesh_1m_mirror", lambda r, t: run_mesh_variant(r, t, "mirror")),
+            ("mesh_1m_glass", lambda r, t: run_mesh_variant(r, t, "glass")))
+    for name, fn in legs:
         try:
             out[name] = fn(rrt, torch)
         except Exception as e:
@@ -272,4 +332,10 @@ if __name__ == "__main__":
         res["mesh_1m_device_lbvh"] = run_mesh(rrt, torch, bvh_builder=1)
     if which in ("all", "photon"):
         res["photon_1m"] = run_photon(rrt, torch)
+    if which in ("all", "csg"):
+        res["csg_1080p"] = run_csg(rrt, torch)
+    if which in ("all", "mirror", "glass"):
+        for v in ("mirror", "glass"):
+            if which in ("all", v):
+                res["mesh_1m_" + v] = run_mesh_variant(rrt, torch, v)
     print(json.dumps(res, indent=1))

@@ -279,6 +279,16 @@ int rrt_render(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t y1, fl
 int rrt_render_device(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t y1, float *rgb_dev,
                       float *depth_dev, uint32_t *object_id_dev, void *hip_stream);
 
+/* Load-balanced variant of the row split for multi-GPU frames (SURVEY.md 8e "tiles round-robin"): renders the image rows
+ * y with (y / group_rows) % group_stride == first_group (rank r of N passes first_group = r, group_stride = N), packed in
+ * ascending order into the outputs ([rows][width] with rows = rrt_interleaved_row_count).  group_rows must be a multiple
+ * of 8.  The reference's own split is contiguous bands (camera.rs:14-31), which leaves ranks with sky idle; pixels are
+ * independent, so every split gives the same frame.  group_stride = 1 renders the whole frame.                     */
+uint32_t rrt_interleaved_row_count(uint32_t height, uint32_t group_rows, uint32_t first_group, uint32_t group_stride);
+int rrt_render_interleaved_device(rrt_scene *s, const rrt_camera *cam, uint32_t group_rows, uint32_t first_group,
+                                  uint32_t group_stride, float *rgb_dev, float *depth_dev, uint32_t *object_id_dev,
+                                  void *hip_stream);
+
 /* replaces: Environment::raytrace (environment.rs:27), batched: n rays, origins/directions
  * [n][3] on the host.                                                                      */
 int rrt_raytrace(rrt_scene *s, const float *origins, const float *directions, size_t n, float *rgb,
@@ -344,6 +354,13 @@ int rrt_photon_local_count(rrt_scene *s, int which, uint64_t *count);
 int rrt_photon_export_device(rrt_scene *s, int which, float *pos4_dev, float *incident4_dev,
                              float *intensity4_dev, uint64_t *meta_dev);
 int rrt_photon_import_device(rrt_scene *s, int which, const float *pos4_dev, const float *incident4_dev,
+                             const float *intensity4_dev, const uint64_t *meta_dev, uint64_t count);
+
+/* The all-gathered map arrives as one segment per rank (a padded all-gather leaves gaps between them): reserve room for
+ * the total once, import the first segment (rrt_photon_import_device, which replaces this rank's own records), append the
+ * others.  Replaces the per-thread Vec concatenation of flatten_photons (photon_scene.rs:114-148).                    */
+int rrt_photon_reserve(rrt_scene *s, int which, uint64_t total);
+int rrt_photon_append_device(rrt_scene *s, int which, const float *pos4_dev, const float *incident4_dev,
                              const float *intensity4_dev, const uint64_t *meta_dev, uint64_t count);
 
 /* PhotonTree::get_within_distance and get_n_within_radius (core/photon_tree.rs:15-35, 41-50), batched: for each of

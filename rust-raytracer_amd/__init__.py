@@ -91,6 +91,10 @@ _sig("rrt_render_device", C.c_int, C.c_void_p, C.POINTER(Camera), C.c_uint32, C.
 _sig("rrt_raytrace", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _f32p, _f32p, _u32p)
 _sig("rrt_trace", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _u32p, _u32p, _f32p, _f32p, _f32p, _f32p)
 _sig("rrt_shadowtrace", C.c_int, C.c_void_p, _f32p, _f32p, _f32p, C.c_size_t, _u8p)
+_sig("rrt_interleaved_row_count", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+_sig("rrt_render_interleaved_device", C.c_int, C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("rrt_photon_reserve", C.c_int, C.c_void_p, C.c_int, C.c_uint64)
+_sig("rrt_photon_append_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 _sig("rrt_trace_noalloc", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _u32p, _u32p, _f32p, _f32p, _f32p, _f32p)
 _sig("rrt_photon_begin", C.c_int, C.c_void_p, C.c_uint64)
 _sig("rrt_photon_shoot", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64)
@@ -111,6 +115,13 @@ _sig("rrt_get_stats", C.c_int, C.c_void_p, C.POINTER(Stats))
 _sig("rrt_quantise", None, _f32p, C.c_size_t, _u8p)
 _sig("rrt_write_rgb_ppm", C.c_int, C.c_char_p, _f32p, C.c_uint32, C.c_uint32)
 _sig("rrt_write_depth_pgm", C.c_int, C.c_char_p, _f32p, C.c_uint32, C.c_uint32)
+
+
+def interleaved_rows(height, group_rows, first_group, group_stride):
+    """Image rows of share `first_group` of `group_stride`, in the order rrt_render_interleaved_device packs them."""
+    rows = [y for y in range(height) if (y // group_rows) % group_stride == first_group]
+    assert len(rows) == lib.rrt_interleaved_row_count(height, group_rows, first_group, group_stride)
+    return np.asarray(rows, np.int64)
 
 
 def last_error():
@@ -270,6 +281,10 @@ class Scene:
     def render_device(self, cam, y0, y1, rgb_ptr, depth_ptr, id_ptr, stream=None):
         check(lib.rrt_render_device(self._h, C.byref(cam), y0, y1, rgb_ptr, depth_ptr, id_ptr, stream))
 
+    def render_interleaved_device(self, cam, group_rows, first_group, group_stride, rgb_ptr, depth_ptr, id_ptr, stream=None):
+        """The image rows y with (y // group_rows) % group_stride == first_group, packed (rrt_render_interleaved_device)."""
+        check(lib.rrt_render_interleaved_device(self._h, C.byref(cam), group_rows, first_group, group_stride, rgb_ptr, depth_ptr, id_ptr, stream))
+
     def raytrace(self, origins, directions):
         o, d = _f32(origins, (-1, 3)), _f32(directions, (-1, 3))
         n = o.shape[0]
@@ -304,6 +319,12 @@ class Scene:
         occ = np.zeros(o.shape[0], np.uint8)
         check(lib.rrt_shadowtrace(self._h, _fp(o), _fp(d), _fp(l), o.shape[0], occ.ctypes.data_as(_u8p)))
         return occ
+
+    def photon_reserve(self, which, total):
+        check(lib.rrt_photon_reserve(self._h, which, total))
+
+    def photon_append_device(self, which, pos_ptr, inc_ptr, rgb_ptr, meta_ptr, count):
+        check(lib.rrt_photon_append_device(self._h, which, pos_ptr, inc_ptr, rgb_ptr, meta_ptr, count))
 
     def photon_begin(self, seed):
         check(lib.rrt_photon_begin(self._h, seed))

@@ -10,6 +10,9 @@ struct DevCamera {
     f3 position, right, up, lookat;
     float fov;
     uint32_t width, height;
+    // interleaved row groups (rrt_render_interleaved_device): the rows being rendered are the image rows y with
+    // (y / row_group) % row_stride == row_first, packed; row_stride <= 1 = a plain band starting at y0
+    uint32_t row_group, row_stride, row_first;
 };
 
 // photon index in HBM (dev_photon.h)

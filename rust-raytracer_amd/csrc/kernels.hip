@@ -86,7 +86,9 @@ __device__ __forceinline__ uint32_t node_pixel(uint32_t g, uint32_t width, uint3
 __device__ __forceinline__ void level_ray(const TraceArgs &A, uint32_t i, f3 &o, f3 &d) {
     if (A.level == 0 && A.cam.width != 0) {
         uint32_t pixel = node_pixel(A.pixel_base + i, A.cam.width, A.band_rows);
-        camera_ray(A.cam, pixel % A.cam.width, A.y0 + pixel / A.cam.width, o, d);
+        uint32_t row = pixel / A.cam.width;  // row of the band (or of the packed rows of an interleaved share)
+        if (A.cam.row_stride > 1) row = ((row / A.cam.row_group) * A.cam.row_stride + A.cam.row_first) * A.cam.row_group + row % A.cam.row_group;
+        camera_ray(A.cam, pixel % A.cam.width, A.y0 + row, o, d);
     } else {
         float4 ro = A.cur.ray_o[i], rd = A.cur.ray_d[i];
         o = mk3(ro.x, ro.y, ro.z);

@@ -823,6 +823,36 @@ int rrt_photon_import_device(rrt_scene *s, int which, const float *pos4_dev, con
     s->maps_built = false;
     return RRT_OK;
 }
+int rrt_photon_reserve(rrt_scene *s, int which, uint64_t total) {
+    if (!s || which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
+    if (total >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
+    PhotonBuffers &b = s->local[which];
+    int rc;
+    const uint64_t need = std::max<uint64_t>(total, 1);
+    if ((rc = grow_preserve(b.pos, need, b.count)) || (rc = grow_preserve(b.dir, need, b.count)) || (rc = grow_preserve(b.rgb, need, b.count)) ||
+        (rc = grow_preserve(b.meta, need, b.count)))
+        return rc;
+    return RRT_OK;
+}
+int rrt_photon_append_device(rrt_scene *s, int which, const float *pos4_dev, const float *incident4_dev, const float *intensity4_dev,
+                             const uint64_t *meta_dev, uint64_t count) {
+    if (!s || which < 0 || which > 1) return fail(RRT_ERR_INVALID, "bad argument");
+    if (int rc_dev = use_scene_device(s)) return rc_dev;
+    if (count == 0) return RRT_OK;
+    if (!pos4_dev || !incident4_dev || !intensity4_dev || !meta_dev) return fail(RRT_ERR_INVALID, "null argument");
+    PhotonBuffers &b = s->local[which];
+    if (b.count + count >= (1ull << 32)) return fail(RRT_ERR_LIMIT, "photon buffer above 2^32 records per GPU");
+    int rc = grow_photons(b, b.count + count);
+    if (rc) return rc;
+    RRT_HIP(hipMemcpy(b.pos.p + b.count, pos4_dev, count * 16, hipMemcpyDeviceToDevice));
+    RRT_HIP(hipMemcpy(b.dir.p + b.count, incident4_dev, count * 16, hipMemcpyDeviceToDevice));
+    RRT_HIP(hipMemcpy(b.rgb.p + b.count, intensity4_dev, count * 16, hipMemcpyDeviceToDevice));
+    RRT_HIP(hipMemcpy(b.meta.p + b.count, meta_dev, count * 8, hipMemcpyDeviceToDevice));
+    b.count += count;
+    s->maps_built = false;
+    return RRT_OK;
+}
 
 int rrt_photon_query(rrt_scene *s, int which, const float *positions, size_t n, float half_width, uint32_t k_max, uint32_t *count, uint64_t *key,
                      float *dist2) {

@@ -1011,6 +1011,9 @@ DevCamera to_dev(const rrt_camera *c) {
     d.fov = c->fov;
     d.width = c->width;
     d.height = c->height;
+    d.row_group = 0;
+    d.row_stride = 1;
+    d.row_first = 0;
     return d;
 }
 
@@ -1243,6 +1246,30 @@ int rrt_render_device(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t
     if (n >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 pixels in one band");
     DevCamera dc = to_dev(cam);
     return render_rays(s, &dc, y0, (uint32_t)n, nullptr, nullptr, rgb_dev, depth_dev, object_id_dev, (hipStream_t)hip_stream);
+}
+
+uint32_t rrt_interleaved_row_count(uint32_t height, uint32_t group_rows, uint32_t first_group, uint32_t group_stride) {
+    if (group_rows == 0 || group_stride == 0 || first_group >= group_stride) return 0;
+    uint32_t rows = 0;
+    for (uint64_t y = (uint64_t)first_group * group_rows; y < height; y += (uint64_t)group_stride * group_rows)
+        rows += (uint32_t)std::min<uint64_t>(group_rows, height - y);
+    return rows;
+}
+
+int rrt_render_interleaved_device(rrt_scene *s, const rrt_camera *cam, uint32_t group_rows, uint32_t first_group, uint32_t group_stride,
+                                  float *rgb_dev, float *depth_dev, uint32_t *object_id_dev, void *hip_stream) {
+    if (!s || !cam) return fail(RRT_ERR_INVALID, "null argument");
+    if (group_rows == 0 || group_rows % 8 != 0) return fail(RRT_ERR_INVALID, "group_rows must be a positive multiple of 8 (the frame is walked in 8x8 tiles)");
+    if (group_stride == 0 || first_group >= group_stride) return fail(RRT_ERR_INVALID, "bad group stride / first group");
+    const uint32_t rows = rrt_interleaved_row_count(cam->height, group_rows, first_group, group_stride);
+    uint64_t n = (uint64_t)rows * cam->width;
+    if (n >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 pixels in one share");
+    if (n == 0) return RRT_OK;
+    DevCamera dc = to_dev(cam);
+    dc.row_group = group_rows;
+    dc.row_stride = group_stride;
+    dc.row_first = first_group;
+    return render_rays(s, &dc, 0, (uint32_t)n, nullptr, nullptr, rgb_dev, depth_dev, object_id_dev, (hipStream_t)hip_stream);
 }
 
 int rrt_render(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t y1, float *rgb, float *depth, uint32_t *object_id) {

@@ -480,3 +480,75 @@ def test_concurrent_render_calls_on_one_handle(repo):
     gpu.pre_render(1)
     for a, b in zip(want[2], gpu.render(cams[2])):
         assert np.array_equal(bits(a), bits(b))
+
+
+def test_set_params_reaches_every_worker_of_concurrent_renders(repo):
+    """Workers leased by concurrent render calls copy mode and params when they are made.  rrt_scene_set_params /
+    rrt_scene_set_mode must drop them: after max_depth changes, every band of a concurrently rendered frame must use the
+    new depth, whichever worker renders it (a stale worker would still bounce five times)."""
+    import threading
+
+    gpu, cam = rrt.Scene.load(os.path.join(repo, "assets/scenes/c2_quadric_csg_fresnel.txt"))
+    gpu.pre_render(1)
+    cam.width, cam.height = 256, 144
+    bands = [(0, 48), (48, 96), (96, 144)]
+
+    def concurrent_frame():
+        parts, errors = [None] * len(bands), []
+
+        def work(j):
+            try:
+                parts[j] = gpu.render(cam, *bands[j])
+            except Exception as e:
+                errors.append(e)
+
+        th = [threading.Thread(target=work, args=(j,)) for j in range(len(bands))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        return [np.concatenate([p[k] for p in parts]) for k in range(3)]
+
+    deep = concurrent_frame()                       # creates the workers, max_depth 5
+    p = rrt.default_params(max_depth=1)
+    gpu.set_params(p)                               # no pre_render in between: scene mode renders with the new values
+    shallow = concurrent_frame()
+    fresh, _ = rrt.Scene.load(os.path.join(repo, "assets/scenes/c2_quadric_csg_fresnel.txt"), params=p)
+    fresh.pre_render(1)
+    want = fresh.render(cam)
+    for a, b in zip(shallow, want):
+        assert np.array_equal(bits(a), bits(b))
+    assert not np.array_equal(bits(deep[0]), bits(shallow[0]))   # the depth really matters in this scene
+
+
+def test_interleaved_row_groups_give_the_same_frame(repo):
+    """rrt_render_interleaved_device (the load-balanced multi-GPU split): the shares of 3 'ranks' in groups of 8 rows, put
+    back in image order, equal the whole frame bit for bit; ragged height (not a multiple of 8 or of 24)."""
+    import torch
+
+    gpu, cam = rrt.Scene.load(os.path.join(repo, "assets/scenes/scene2.txt"), mode_override=abi.MODE_SCENE)
+    gpu.pre_render(1)
+    cam.width, cam.height = 200, 117
+    want = gpu.render(cam)
+    got = [np.zeros_like(w) for w in want]
+    seen = np.zeros(cam.height, int)
+    for world, group in ((3, 8), (2, 16), (1, 8)):
+        seen[:] = 0
+        for r in range(world):
+            rows = rrt.interleaved_rows(cam.height, group, r, world)
+            n = len(rows)
+            rgb = torch.full((max(n, 1), cam.width, 3), -7.0, dtype=torch.float32, device="cuda")
+            depth = torch.full((max(n, 1), cam.width), -7.0, dtype=torch.float32, device="cuda")
+            ids = torch.full((max(n, 1), cam.width), 123, dtype=torch.int32, device="cuda")
+            gpu.render_interleaved_device(cam, group, r, world, rgb.data_ptr(), depth.data_ptr(), ids.data_ptr(), None)
+            torch.cuda.synchronize()
+            got[0][rows], got[1][rows], got[2][rows] = rgb[:n].cpu().numpy(), depth[:n].cpu().numpy(), ids[:n].cpu().numpy().view(np.uint32)
+            seen[rows] += 1
+        assert (seen == 1).all()
+        for a, b in zip(got, want):
+            assert np.array_equal(bits(a), bits(b)), (world, group)
+    with pytest.raises(rrt.RrtError):
+        gpu.render_interleaved_device(cam, 12, 0, 2, 0, 0, 0, None)     # groups are whole 8-row tiles
+    with pytest.raises(rrt.RrtError):
+        gpu.render_interleaved_device(cam, 8, 2, 2, 0, 0, 0, None)      # first group must be below the stride

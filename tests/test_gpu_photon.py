@@ -288,3 +288,56 @@ def test_scene2_at_the_reference_settings_lies_inside_the_reference_noise_envelo
     assert np.array_equal(rrt.quantise(depth), dref)
     st = gpu.stats()
     assert st["photons_emitted"] == 5_010_000 and st["photons_stored_regular"] > 5_000_000
+
+
+def test_exchange_buffers_are_exactly_as_large_as_the_header_says(repo):
+    """include/rrt.h: the exchange arrays are float4 records — count * 16 bytes per float4 array, count * 8 per key / meta
+    array.  Exports into exactly-sized buffers must leave the canaries behind them untouched, and what they wrote must
+    import again (segment by segment: import + append) into the same maps."""
+    import torch
+
+    _, a, cam = pair(repo, "pm_caustics", 20000, 1500)
+    _, b, _ = pair(repo, "pm_caustics", 20000, 1500)
+    a.pre_render(5)
+    CANARY = 64
+
+    def guarded(n_elems, dtype):
+        t = torch.full((n_elems + CANARY,), 77, dtype=dtype, device="cuda")
+        return t
+
+    def intact(t, n_elems):
+        return bool((t[n_elems:] == 77).all().item())
+
+    b.photon_begin(5)
+    b.photon_shoot(0, 0, 0, 20000)
+    n = a.caustic_count(0)
+    assert n > 0
+    pos, inc, key = guarded(4 * n, torch.float32), guarded(4 * n, torch.float32), guarded(n, torch.int64)
+    a.caustic_export_device(0, pos.data_ptr(), inc.data_ptr(), key.data_ptr())
+    torch.cuda.synchronize()
+    assert intact(pos, 4 * n) and intact(inc, 4 * n) and intact(key, n)
+    assert not bool((pos[4 * n - 4: 4 * n] == 77).all().item())        # ... and the last record really was written
+    b.caustic_import_device(0, pos.data_ptr(), inc.data_ptr(), key.data_ptr(), n)
+    b.photon_shoot(0, 1, 0, 1500)
+    for which in (0, 1):
+        n = a.photon_count(which)
+        arrs = [guarded(4 * n, torch.float32) for _ in range(3)] + [guarded(n, torch.int64)]
+        a.photon_export_device(which, *(t.data_ptr() for t in arrs))
+        torch.cuda.synchronize()
+        for t, k in zip(arrs, (4 * n, 4 * n, 4 * n, n)):
+            assert intact(t, k)
+        # back in as three segments of ragged length, as an all-gather into padded buffers leaves them
+        cuts = [0, n // 3, n // 3 + 1, n]
+        b.photon_reserve(which, n)
+        for j in range(3):
+            lo, hi = cuts[j], cuts[j + 1]
+            ptrs = [arrs[0].data_ptr() + lo * 16, arrs[1].data_ptr() + lo * 16, arrs[2].data_ptr() + lo * 16, arrs[3].data_ptr() + lo * 8]
+            (b.photon_import_device if j == 0 else b.photon_append_device)(which, *ptrs, hi - lo)
+        assert b.photon_count(which) == n
+    b.photon_build()
+    cam.width = cam.height = 64
+    assert np.array_equal(bits(a.render(cam)[0]), bits(b.render(cam)[0]))
+    for which in (0, 1):
+        pa, pb = a.photon_read(which), b.photon_read(which)
+        for k in pa:
+            assert np.array_equal(pa[k].view(np.uint8), pb[k].view(np.uint8)), (which, k)

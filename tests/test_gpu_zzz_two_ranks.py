@@ -21,3 +21,30 @@ def test_two_ranks_equal_one_rank_on_device(repo):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=repo)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "two ranks == one rank" in out.stdout and "bit for bit" in out.stdout
+
+
+def test_bench_with_two_ranks_measures_both_splits(repo):
+    """bench.py --gpus 2 in rehearsal mode (both ranks on the box's one GPU, gloo + host staging instead of RCCL): the row
+    shares of the 4K mesh frame with their gather to rank 0, and the photon pass with its all-gather; the JSON line must
+    carry the collective figures and the ray total of a whole frame."""
+    import json
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RRT_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--photons-per-rank", "200000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=repo, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 4
+    assert j["collective_ms"] >= 0.0 and j["collective_gb_per_s"] is not None
+    assert 15_000_000 < j["config"]["rays_per_frame"] < 16_500_000          # both shares add up to the whole frame
+    p = j["extra"]["photon_pass"]
+    assert "error" not in p, p
+    assert p["collective_bytes"] > 0 and p["collective_ms"] > 0 and p["records"] > 400000
+    for k in ("shoot", "allgather_seeds", "allgather_maps", "import", "build", "render_share", "gather_frame"):
+        assert k in p["ms"], k

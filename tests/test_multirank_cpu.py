@@ -1,8 +1,9 @@
 """The N>1 host path on CPU: world_size-2 gloo, the oracle standing in for the device.
 
 Exercises rust-raytracer_amd/distributed.py (index-range sharding, the two variable-length
-all-gathers, band split of the render) with CPU tensors; on the GPU box the same code runs over
-RCCL with DevicePhotonExchange.
+all-gathers into preallocated segment buffers, the row shares of a frame — contiguous bands and
+interleaved 8-row groups — and their gather to rank 0) with CPU tensors; on the GPU box the same code
+runs over RCCL with DevicePhotonExchange and device buffers.
 """
 import importlib
 import os
@@ -29,14 +30,28 @@ class OracleExchange:
     def _t(a):
         return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a)
 
-    def seeds(self, light):
-        return tuple(self._t(a) for a in self.scene.caustic_export(light))
+    @staticmethod
+    def _pad(t, cap):
+        if cap is None or cap == t.shape[0]:
+            return t
+        out = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype)
+        out[: t.shape[0]] = t
+        return out
+
+    def seed_count(self, light):
+        return self.scene.caustic_count(light)
+
+    def record_count(self, which):
+        return self.scene.photon_count(which)
+
+    def seeds(self, light, cap=None):
+        return tuple(self._pad(self._t(a), cap) for a in self.scene.caustic_export(light))
 
     def set_seeds(self, light, pos, inc, key):
         self.scene.caustic_import(light, pos.numpy(), inc.numpy(), key.numpy().view(np.uint64))
 
-    def records(self, which):
-        return tuple(self._t(a) for a in self.scene.photon_export(which))
+    def records(self, which, cap=None):
+        return tuple(self._pad(self._t(a), cap) for a in self.scene.photon_export(which))
 
     def set_records(self, which, pos, inc, rgb, meta):
         self.scene.photon_import(which, pos.numpy(), inc.numpy(), rgb.numpy(), meta.numpy().view(np.uint64))
@@ -60,13 +75,30 @@ def _worker(rank, world, port, out_dir):
     try:
         ob, s, cam = _scene()
         D = importlib.import_module("rust-raytracer_amd.distributed")
-        D.photon_pass(s, OracleExchange(s), 1, N_PHOTONS, N_CAUSTIC, SEED, rank, world, dist, "cpu")
-        y0, y1 = D.row_band(cam.height, rank, world)
-        rgb, depth, ids = s.render(cam, y0, y1, threads=1)
-        (rgb_all, depth_all), counts = D.all_gather_variable((torch.from_numpy(rgb), torch.from_numpy(depth)), dist, "cpu")
+        info = D.photon_pass(s, OracleExchange(s), 1, N_PHOTONS, N_CAUSTIC, SEED, rank, world, dist, "cpu")
+        assert info["bytes"]["allgather_maps"] > 0 and "allgather_seeds" in info["ms"]
+        frames = {}
+        for interleave in (0, 8):   # contiguous bands (camera.rs:14-31), then 8-row groups dealt round-robin
+            fg = D.FrameGather(ob.rrt, cam, rank, world, dist, "cpu", interleave=interleave)
+            W, plane = cam.width, fg.plane
+            rows = fg.rows[rank]
+            # the oracle renders [y0, y1) bands: one call per run of consecutive rows of this rank's share
+            runs = np.split(rows, np.where(np.diff(rows) != 1)[0] + 1) if len(rows) else []
+            parts = [s.render(cam, int(r[0]), int(r[-1]) + 1, threads=1) for r in runs]
+            rgb, depth, ids = (np.concatenate([p[k] for p in parts]) for k in range(3))
+            n = len(rows) * W
+            fg.local[0][: 3 * n] = torch.from_numpy(rgb.reshape(-1))
+            fg.local[0][3 * plane: 3 * plane + n] = torch.from_numpy(depth.reshape(-1))
+            fg.local[0][4 * plane: 4 * plane + n] = torch.from_numpy(ids.reshape(-1).view(np.float32))
+            fg.start_gather(0)
+            out = fg.finish(0)
+            if rank == 0:
+                frames["rgb%d" % interleave], frames["depth%d" % interleave] = out[0].numpy().copy(), out[1].numpy().copy()
+                frames["ids%d" % interleave] = out[2].numpy().copy()
+                frames["rows%d" % interleave] = np.array(fg.n_rows)
         if rank == 0:
-            np.savez(os.path.join(out_dir, "multi.npz"), rgb=rgb_all.numpy(), depth=depth_all.numpy(), counts=np.array(counts),
-                     n0=s.photon_count(0), n1=s.photon_count(1), key0=s.photon_read(0)["key"], pos1=s.photon_read(1)["position"])
+            np.savez(os.path.join(out_dir, "multi.npz"), n0=s.photon_count(0), n1=s.photon_count(1), key0=s.photon_read(0)["key"],
+                     pos1=s.photon_read(1)["position"], **frames)
     finally:
         dist.destroy_process_group()
 
@@ -90,10 +122,13 @@ def test_two_ranks_equal_one_rank(tmp_path):
     ob, s, cam = _scene()
     s.pre_render(SEED, threads=2)
     rgb, depth, ids = s.render(cam, threads=2)
-    assert list(multi["counts"]) == [18, 19]  # 37 rows: 18 + (18 + remainder 1)
+    assert list(multi["rows0"]) == [18, 19]  # 37 rows in bands: 18 + (18 + remainder 1)
+    assert list(multi["rows8"]) == [21, 16]  # 8-row groups 0, 2, 4 (the last one 5 rows) and 1, 3
     assert int(multi["n0"]) == s.photon_count(0) and int(multi["n1"]) == s.photon_count(1) and int(multi["n0"]) > N_PHOTONS // 2
     assert np.array_equal(multi["key0"], s.photon_read(0)["key"])
     assert np.array_equal(multi["pos1"].view(np.uint32), s.photon_read(1)["position"].view(np.uint32))
-    assert np.array_equal(multi["depth"].view(np.uint32), depth.view(np.uint32))
-    # same photon set, same query order inside the oracle (it sorts by distance): bit-identical frames
-    assert np.array_equal(multi["rgb"].view(np.uint32), rgb.view(np.uint32))
+    for k in ("0", "8"):
+        assert np.array_equal(multi["depth" + k].view(np.uint32), depth.view(np.uint32))
+        assert np.array_equal(multi["ids" + k].view(np.uint32), ids)
+        # same photon set, same query order inside the oracle (it sorts by distance): bit-identical frames
+        assert np.array_equal(multi["rgb" + k].view(np.uint32), rgb.view(np.uint32))

@@ -1,7 +1,8 @@
 """Two ranks SHARING one GPU rehearse the multi-GPU photon path end to end on the device (the real job uses one GPU per
 rank and RCCL; two ranks on one device must use gloo, so the arrays are staged through host memory here):
 photon index ranges per rank -> all-gather of the pass-1 caustic photons -> pass 2 -> all-gather of both maps -> every
-rank builds the index -> every rank renders its row band -> rank 0 compares with a single-rank run, bit for bit.
+rank builds the index -> every rank renders its share of the frame's rows (bands, then interleaved groups) -> one gather to rank 0, which compares with a single-rank
+run, bit for bit.
    torchrun --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/two_rank_photon_rehearsal.py"""
 import importlib, os, sys
 import numpy as np
@@ -23,29 +24,25 @@ path = os.path.join(REPO, "assets/scenes/pm_caustics.txt")
 scene, cam = rrt.Scene.load(path, params=params, mode_override=abi.MODE_PHOTON)
 
 
-class Staged(D.DevicePhotonExchange):
-    """gloo hands back host tensors: put them on the device before librrt reads them"""
-
-    def set_seeds(self, light, pos, inc, key):
-        super().set_seeds(light, pos.cuda(), inc.cuda(), key.cuda())
-
-    def set_records(self, which, pos, inc, rgb, meta):
-        super().set_records(which, pos.cuda(), inc.cuda(), rgb.cuda(), meta.cuda())
-
-
-D.photon_pass(scene, Staged(scene, "cuda"), 1, PHOTONS, CAUSTIC, SEED, rank=rank, world=world, dist=dist, device="cpu")
-cam.width, cam.height = 320, 240
-y0, y1 = D.row_band(cam.height, rank, world)
-rgb, depth, ids = scene.render(cam, y0, y1)
-parts = [None] * world
-dist.gather_object((rgb, depth, ids), parts if rank == 0 else None, dst=0)
+info = D.photon_pass(scene, D.StagedPhotonExchange(scene, "cuda"), 1, PHOTONS, CAUSTIC, SEED, rank=rank, world=world, dist=dist, device="cpu")
+cam.width, cam.height = 320, 236   # 29.5 groups of 8 rows: ragged shares
+frames = {}
+for interleave in (0, 8):         # contiguous bands, then 8-row groups dealt round-robin (rrt_render_interleaved_device)
+    fg = D.FrameGather(rrt, cam, rank, world, dist, "cuda", interleave=interleave, stage_host=True)
+    fg.render(scene, cam, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    fg.start_gather(0)
+    out = fg.finish(0)
+    if rank == 0:
+        frames[interleave] = tuple(t.numpy().copy() for t in out)
 if rank == 0:
     one, _ = rrt.Scene.load(path, params=params, mode_override=abi.MODE_PHOTON)
     one.pre_render(SEED)
     want = one.render(cam)
-    for k, name in enumerate(("rgb", "depth", "id")):
-        got = np.concatenate([p[k] for p in parts])
-        assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), name
+    for interleave, got in frames.items():
+        for k, name in enumerate(("rgb", "depth", "id")):
+            assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (interleave, name)
+    assert info["bytes"]["allgather_maps"] > 0
     for which in (0, 1):
         a, b = one.photon_read(which), scene.photon_read(which)
         assert len(a["key"]) > 0
