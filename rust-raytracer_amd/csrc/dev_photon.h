@@ -1,8 +1,8 @@
-// dev_photon.h — counter-based RNG streams, the photon hash grid and the radiance-estimate gather.
+// dev_photon.h — counter-based RNG streams, the photon index and the radiance-estimate gather.
 //
 // Replaces core/photon_tree.rs (third-party kd-tree 0.5.1, `within` = closed axis-aligned box) with
-// a uniform hash grid whose cell edge equals the box edge (2 * half_width): a query box overlaps at
-// most 2 (rarely 3) cells per axis.  Records are sorted by cell so a query streams contiguous runs.
+// a dense uniform grid (cell edge = half_width) over the region that holds the photons, plus a hash
+// grid for the few that lie outside it.  Records are sorted by cell so a query streams contiguous runs.
 #pragma once
 #include "kernels.h"
 
@@ -87,7 +87,16 @@ struct GatherSums {
     uint32_t candidates;
 };
 
-// cell key -> (first record, count) through the open-addressing table
+// ---- the index: a dense grid where the photons are, a hash grid for the stragglers ---------------------------------
+// Dense part: cells of edge r (the query half width) over the box that holds all but the outermost photons (the
+// reference's infinite planes catch photons millions of units out).  Records are sorted by cell with x running fastest,
+// so the cells a query box [p - r, p + r] overlaps along x (3, rarely 4) are ONE contiguous run of records per (y, z) row:
+// 9 runs per query, each found with two loads from the start table at computed addresses — no probing — and the records
+// read cover 3 x 3 x 3 cells of edge r instead of 2 x 2 x 2 cells of edge 2r (2.25 x instead of 4 x the query's own area
+// on a surface).  Outliers: the hash grid of round 1 (cell edge 2r, open addressing), consulted only by queries whose box
+// leaves the dense region.
+
+// cell key -> (first record, count) through the open-addressing table of the outliers
 __device__ __forceinline__ uint2 lookup_cell(const DevPhotonMap &G, uint64_t key) {
     uint32_t slot = hash_key(key) & G.table_mask;
     for (;;) {
@@ -96,6 +105,36 @@ __device__ __forceinline__ uint2 lookup_cell(const DevPhotonMap &G, uint64_t key
         if (k == ~0ULL) return make_uint2(0, 0);
         slot = (slot + 1) & G.table_mask;
     }
+}
+
+// dense cell coordinate along one axis as a float (NaN for NaN input): the same function files records and places queries
+RRT_HD float dense_coord(float x, float lo, float inv_cell) { return floorf((x - lo) * inv_cell); }
+
+// The dense cells a box overlaps: [x0, x1] x [y0, y1] x [z0, z1] clamped to the grid (empty when x1 < x0 ...), and whether
+// the box reaches outside the grid (then the outliers' hash grid has to be asked as well).
+struct DenseBox {
+    int x0, x1, y0, y1, z0, z1;
+    bool outside, empty;
+};
+__device__ __forceinline__ DenseBox dense_box(const DevPhotonMap &G, f3 lo, f3 hi) {
+    DenseBox B;
+    const float fx0 = dense_coord(lo.x, G.dlo_x, G.inv_dcell), fx1 = dense_coord(hi.x, G.dlo_x, G.inv_dcell);
+    const float fy0 = dense_coord(lo.y, G.dlo_y, G.inv_dcell), fy1 = dense_coord(hi.y, G.dlo_y, G.inv_dcell);
+    const float fz0 = dense_coord(lo.z, G.dlo_z, G.inv_dcell), fz1 = dense_coord(hi.z, G.dlo_z, G.inv_dcell);
+    const float nx = (float)G.nx, ny = (float)G.ny, nz = (float)G.nz;
+    // written so that a NaN coordinate counts as outside
+    B.outside = !(fx0 >= 0.0f && fx1 < nx && fy0 >= 0.0f && fy1 < ny && fz0 >= 0.0f && fz1 < nz);
+    B.empty = !(fx1 >= 0.0f && fx0 < nx && fy1 >= 0.0f && fy0 < ny && fz1 >= 0.0f && fz0 < nz) || G.n_dense == 0;
+    B.x0 = (int)fminf(fmaxf(fx0, 0.0f), nx - 1.0f), B.x1 = (int)fminf(fmaxf(fx1, 0.0f), nx - 1.0f);
+    B.y0 = (int)fminf(fmaxf(fy0, 0.0f), ny - 1.0f), B.y1 = (int)fminf(fmaxf(fy1, 0.0f), ny - 1.0f);
+    B.z0 = (int)fminf(fmaxf(fz0, 0.0f), nz - 1.0f), B.z1 = (int)fminf(fmaxf(fz1, 0.0f), nz - 1.0f);
+    return B;
+}
+// the records of row (y, z), cells x0..x1: one contiguous run
+__device__ __forceinline__ uint2 dense_run(const DevPhotonMap &G, int x0, int x1, int y, int z) {
+    const uint32_t row = ((uint32_t)z * G.ny + (uint32_t)y) * G.nx;
+    const uint32_t first = G.dense_start[row + (uint32_t)x0], end = G.dense_start[row + (uint32_t)x1 + 1u];
+    return make_uint2(first, end - first);
 }
 
 // closed-box test of one candidate record; incident / intensity are read for the records inside only
@@ -110,7 +149,7 @@ __device__ __forceinline__ void take_record(const DevPhotonMap &G, uint32_t i, f
 }
 __device__ __forceinline__ void stream_cell(const DevPhotonMap &G, uint2 range, f3 lo, f3 hi, GatherSums &s) {
     s.candidates += range.y;
-    uint32_t i = range.x, end = range.x + range.y;
+    uint32_t i = min(range.x, G.count), end = i + min(range.y, G.count - i);  // guard: stay inside the map
     for (; i + 4 <= end; i += 4) {  // four independent position loads in flight
         float4 q0 = G.pos_cell[i], q1 = G.pos_cell[i + 1], q2 = G.pos_cell[i + 2], q3 = G.pos_cell[i + 3];
         take_record(G, i, q0, lo, hi, s);
@@ -121,57 +160,59 @@ __device__ __forceinline__ void stream_cell(const DevPhotonMap &G, uint2 range, 
     for (; i < end; i++) take_record(G, i, G.pos_cell[i], lo, hi, s);
 }
 
+// the outliers a box may hold: the hash cells (edge 2r) it overlaps
+template <class F>
+__device__ __forceinline__ void visit_outlier_cells(const DevPhotonMap &G, f3 lo, f3 hi, F &&f) {
+    if (G.n_dense == G.count) return;
+    uint32_t x0 = cell_coord(lo.x, G.inv_cell), x1 = cell_coord(hi.x, G.inv_cell);
+    uint32_t y0 = cell_coord(lo.y, G.inv_cell), y1 = cell_coord(hi.y, G.inv_cell);
+    uint32_t z0 = cell_coord(lo.z, G.inv_cell), z1 = cell_coord(hi.z, G.inv_cell);
+    for (uint32_t cx = x0; cx <= x1; cx++)
+        for (uint32_t cy = y0; cy <= y1; cy++)
+            for (uint32_t cz = z0; cz <= z1; cz++) f(lookup_cell(G, cell_key(cx, cy, cz)));
+}
+// every run of records that may hold photons of the closed box [lo, hi]: dense rows in (z, y) order, then outlier cells
+template <class F>
+__device__ __forceinline__ void visit_runs(const DevPhotonMap &G, f3 lo, f3 hi, F &&f) {
+    if (G.count == 0) return;
+    const DenseBox B = dense_box(G, lo, hi);
+    if (!B.empty)
+        for (int z = B.z0; z <= B.z1; z++)
+            for (int y = B.y0; y <= B.y1; y++) f(dense_run(G, B.x0, B.x1, y, z));
+    if (B.outside) visit_outlier_cells(G, lo, hi, f);
+}
+
 // PhotonTree::get_within_distance (photon_tree.rs:15-35) + the accumulation of
 // average_photon_of_type_at (photon_scene.rs:401-407).  The reference adds in order of distance,
-// this adds in cell order: same set, f32 sums differ by rounding only.
+// this adds in index order: same set, f32 sums differ by rounding only.
 __device__ __forceinline__ void gather_box(const DevPhotonMap &G, f3 p, float r, GatherSums &s) {
     s.ldir = mk3(0.0f, 0.0f, 0.0f);
     s.intensity = mk3(0.0f, 0.0f, 0.0f);
     s.k = 0;
     s.candidates = 0;
-    if (G.count == 0) return;
     f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);  // photon_tree.rs:16-18
-    uint32_t x0 = cell_coord(lo.x, G.inv_cell), x1 = cell_coord(hi.x, G.inv_cell);
-    uint32_t y0 = cell_coord(lo.y, G.inv_cell), y1 = cell_coord(hi.y, G.inv_cell);
-    uint32_t z0 = cell_coord(lo.z, G.inv_cell), z1 = cell_coord(hi.z, G.inv_cell);
-    // Two phases, so that the memory system sees independent requests instead of one dependent chain per lane:
-    // first every overlapped cell's (first, count) is looked up, then the cells are streamed four records at a time.
-    // The order of accumulation (cells x-major, records ascending) is the same either way.
-    const bool small = x1 - x0 <= 1u && y1 - y0 <= 1u && z1 - z0 <= 1u;  // cell edge = 2r: always, barring rounding
-    if (small) {
-        uint2 rg[8];
-#pragma unroll
-        for (uint32_t c = 0; c < 8; c++) {
-            uint32_t cx = x0 + (c >> 2), cy = y0 + ((c >> 1) & 1u), cz = z0 + (c & 1u);
-            rg[c] = (cx <= x1 && cy <= y1 && cz <= z1) ? lookup_cell(G, cell_key(cx, cy, cz)) : make_uint2(0, 0);
-        }
-#pragma unroll
-        for (uint32_t c = 0; c < 8; c++) stream_cell(G, rg[c], lo, hi, s);
-    } else {
-        for (uint32_t cx = x0; cx <= x1; cx++)
-            for (uint32_t cy = y0; cy <= y1; cy++)
-                for (uint32_t cz = z0; cz <= z1; cz++) stream_cell(G, lookup_cell(G, cell_key(cx, cy, cz)), lo, hi, s);
-    }
+    visit_runs(G, lo, hi, [&](uint2 run) { stream_cell(G, run, lo, hi, s); });
 }
 
-// the 2 x 2 x 2 cells a query box overlaps (cell edge = box edge), looked up; false when rounding made it 3 along an axis
+// The common query: the box lies inside the dense region and overlaps at most 3 x 3 rows.  Its runs are looked up first
+// (independent loads, and the candidate count is known before a record is read: the heavy-query decision), then streamed.
 struct CellSet {
-    uint2 rg[8];
+    uint2 rg[9];
     uint32_t candidates;
 };
 __device__ __forceinline__ bool lookup_cells(const DevPhotonMap &G, f3 lo, f3 hi, CellSet &C) {
     C.candidates = 0;
 #pragma unroll
-    for (uint32_t c = 0; c < 8; c++) C.rg[c] = make_uint2(0, 0);
+    for (uint32_t c = 0; c < 9; c++) C.rg[c] = make_uint2(0, 0);
     if (G.count == 0) return true;
-    uint32_t x0 = cell_coord(lo.x, G.inv_cell), x1 = cell_coord(hi.x, G.inv_cell);
-    uint32_t y0 = cell_coord(lo.y, G.inv_cell), y1 = cell_coord(hi.y, G.inv_cell);
-    uint32_t z0 = cell_coord(lo.z, G.inv_cell), z1 = cell_coord(hi.z, G.inv_cell);
-    if (!(x1 - x0 <= 1u && y1 - y0 <= 1u && z1 - z0 <= 1u)) return false;
+    const DenseBox B = dense_box(G, lo, hi);
+    if (B.outside && G.n_dense != G.count) return false;  // may hold outliers: the general walk
+    if (B.empty) return true;
+    if (B.y1 - B.y0 > 2 || B.z1 - B.z0 > 2) return false;  // rounding made it 4 cells along an axis
 #pragma unroll
-    for (uint32_t c = 0; c < 8; c++) {
-        uint32_t cx = x0 + (c >> 2), cy = y0 + ((c >> 1) & 1u), cz = z0 + (c & 1u);
-        if (cx <= x1 && cy <= y1 && cz <= z1) C.rg[c] = lookup_cell(G, cell_key(cx, cy, cz));
+    for (int c = 0; c < 9; c++) {
+        const int y = B.y0 + c % 3, z = B.z0 + c / 3;
+        if (y <= B.y1 && z <= B.z1) C.rg[c] = dense_run(G, B.x0, B.x1, y, z);
         C.candidates += C.rg[c].y;
     }
     return true;
@@ -182,7 +223,7 @@ __device__ __forceinline__ void stream_cells(const DevPhotonMap &G, const CellSe
     s.k = 0;
     s.candidates = 0;
 #pragma unroll
-    for (uint32_t c = 0; c < 8; c++) stream_cell(G, C.rg[c], lo, hi, s);
+    for (uint32_t c = 0; c < 9; c++) stream_cell(G, C.rg[c], lo, hi, s);
 }
 
 // the blend of average_photon_at (photon_scene.rs:363-420) from the two maps' sums
@@ -218,7 +259,7 @@ __device__ __forceinline__ int average_photon_at(const DevPhotonMap maps[2], f3 
         if (c0.candidates + c1.candidates > defer_above) return 2;
         stream_cells(maps[0], c0, lo, hi, reg);
         stream_cells(maps[1], c1, lo, hi, cau);
-    } else {  // a box that touches 3 cells along an axis (rounding): the general walk
+    } else {  // a box that leaves the dense region, or touches 4 cells along an axis (rounding): the general walk
         gather_box(maps[0], p, r, reg);
         gather_box(maps[1], p, r, cau);
     }
@@ -238,7 +279,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 __device__ __forceinline__ void wave_gather_box(const DevPhotonMap &G, f3 p, float r, GatherSums &s) {
     f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);
     CellSet C;
-    if (!lookup_cells(G, lo, hi, C)) {  // rounding made the box touch 3 cells along an axis: every lane does the general walk
+    if (!lookup_cells(G, lo, hi, C)) {  // outliers, or 4 cells along an axis: every lane does the general walk
         gather_box(G, p, r, s);
         return;
     }
@@ -249,7 +290,7 @@ __device__ __forceinline__ void wave_gather_box(const DevPhotonMap &G, f3 p, flo
     part.candidates = 0;
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-    for (uint32_t c = 0; c < 8; c++) {
+    for (uint32_t c = 0; c < 9; c++) {
         const uint32_t first = min(C.rg[c].x, G.count), n = min(C.rg[c].y, G.count - first);  // guard: stay inside the map
         for (uint32_t k = lane; k < n; k += 64u) take_record(G, first + k, G.pos_cell[first + k], lo, hi, part);
     }

@@ -17,14 +17,20 @@ struct DevCamera {
 
 // photon index in HBM (dev_photon.h)
 struct DevPhotonMap {
-    const float4 *pos_cell;  // [n] position.xyz, w unused (cell-sorted)
+    const float4 *pos_cell;  // [n] position.xyz, w unused (cell-sorted: dense cells first, then the outliers' hash cells)
     const float4 *incident;  // [n] normalised-again incident.xyz (photon_scene.rs:405), w unused
     const float4 *intensity; // [n] intensity.rgb
-    const uint64_t *keys;    // [table_size] open-addressing hash table: cell key or ~0
-    const uint2 *ranges;     // [table_size] (first, count)
+    const uint64_t *keys;    // [table_size] open-addressing hash table of the outliers: cell key or ~0
+    const uint2 *ranges;     // [table_size] (first, count), absolute record indices
     uint32_t table_mask;
     uint32_t count;
-    float inv_cell;
+    float inv_cell;          // hash grid: 1 / (2 * half_width)
+    // dense grid over [dlo, dlo + n * cell): cell (x, y, z) holds records [dense_start[i], dense_start[i + 1]), i = (z * ny + y) * nx + x
+    const uint32_t *dense_start;  // [nx * ny * nz + 1]
+    uint32_t nx, ny, nz;
+    uint32_t n_dense;        // records [0, n_dense) lie in dense cells, [n_dense, count) are outliers
+    float dlo_x, dlo_y, dlo_z;
+    float inv_dcell;         // 1 / half_width
 };
 
 // error bits of TraceArgs::err (1, 2, 4: dev_shade.h)

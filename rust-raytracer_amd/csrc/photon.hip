@@ -13,6 +13,8 @@
 //                   -> gather into cell order -> open-addressing table cell -> (first, count).
 #include <string.h>
 
+#include <array>
+
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "dev_photon.h"
@@ -275,12 +277,51 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
 }
 
 // ---- index build kernels ------------------------------------------------------------------------------
-__global__ void k_cell_keys(const float4 *pos, uint32_t n, float inv_cell, uint64_t *keys, uint32_t *idx) {
+// sort key of a record: its dense cell index (x fastest), or bit 63 + its hash cell for records outside the dense region
+#define PH_OUTLIER_BIT (1ULL << 63)
+__global__ void k_cell_keys(const float4 *pos, uint32_t n, DevPhotonMap G, uint64_t *keys, uint32_t *idx) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = pos[i];
-    keys[i] = cell_key(cell_coord(p.x, inv_cell), cell_coord(p.y, inv_cell), cell_coord(p.z, inv_cell));
+    const float fx = dense_coord(p.x, G.dlo_x, G.inv_dcell), fy = dense_coord(p.y, G.dlo_y, G.inv_dcell), fz = dense_coord(p.z, G.dlo_z, G.inv_dcell);
+    if (fx >= 0.0f && fx < (float)G.nx && fy >= 0.0f && fy < (float)G.ny && fz >= 0.0f && fz < (float)G.nz)
+        keys[i] = ((uint64_t)(uint32_t)fz * G.ny + (uint32_t)fy) * G.nx + (uint32_t)fx;
+    else
+        keys[i] = PH_OUTLIER_BIT | cell_key(cell_coord(p.x, G.inv_cell), cell_coord(p.y, G.inv_cell), cell_coord(p.z, G.inv_cell));
     idx[i] = i;
+}
+// every `stride`-th position, for the host's choice of the dense region
+__global__ void k_sample_positions(const float4 *pos, uint32_t n, uint32_t stride, uint32_t n_samples, float4 *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_samples) out[i] = pos[min((uint64_t)i * stride, (uint64_t)n - 1)];
+}
+// start[c] = first record (of the sorted keys) whose dense cell is >= c, for c = 0 .. cells; n_dense = first outlier
+__global__ void k_dense_starts(const uint64_t *keys, uint32_t n, uint32_t cells, uint32_t *start, uint32_t *n_dense) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > cells) return;
+    const uint64_t want = c == cells ? PH_OUTLIER_BIT : (uint64_t)c;  // every dense key is below `cells`
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (keys[mid] < want)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    start[c] = lo;
+    if (c == cells) *n_dense = lo;
+}
+// sum of count^2 over the dense cells, into 64 line-separated partial sums
+__global__ void k_dense_crowding(const uint32_t *start, uint32_t cells, unsigned long long *acc) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (c < cells) {
+        unsigned long long k = start[c + 1] - start[c];
+        v = k * k;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&acc[(blockIdx.x & 63u) * 8u], v);
 }
 __global__ void k_iota(uint32_t *idx, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,7 +360,8 @@ __global__ void k_fill_u64(uint64_t *p, uint32_t n, uint64_t v) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-__global__ void k_insert_cells(const uint64_t *keys, uint32_t n, uint64_t *table_keys, uint2 *ranges, uint32_t mask) {
+// keys = the outliers' part of the sorted keys (record `base` onwards); the table holds absolute record indices
+__global__ void k_insert_cells(const uint64_t *keys, uint32_t n, uint32_t base, uint64_t *table_keys, uint2 *ranges, uint32_t mask) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t key = keys[i];
@@ -333,24 +375,16 @@ __global__ void k_insert_cells(const uint64_t *keys, uint32_t n, uint64_t *table
         else
             hi = mid;
     }
-    uint32_t slot = hash_key(key) & mask;
+    const uint64_t cell = key & ~PH_OUTLIER_BIT;  // what lookup_cell is asked for
+    uint32_t slot = hash_key(cell) & mask;
     for (;;) {
-        unsigned long long prev = atomicCAS((unsigned long long *)&table_keys[slot], ~0ULL, (unsigned long long)key);
+        unsigned long long prev = atomicCAS((unsigned long long *)&table_keys[slot], ~0ULL, (unsigned long long)cell);
         if (prev == ~0ULL) {
-            ranges[slot] = make_uint2(i, lo - i);
+            ranges[slot] = make_uint2(base + i, lo - i);
             return;
         }
         slot = (slot + 1) & mask;
     }
-}
-// sum of count^2 over the occupied cells of the table, into 64 line-separated partial sums
-__global__ void k_cell_crowding(const uint64_t *table_keys, const uint2 *ranges, uint32_t size, unsigned long long *acc) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long v = 0;
-    if (i < size && table_keys[i] != ~0ULL) v = (unsigned long long)ranges[i].y * ranges[i].y;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&acc[(blockIdx.x & 63u) * 8u], v);
 }
 __global__ void k_strip_key(const uint64_t *meta, uint32_t n, uint64_t *key) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -367,34 +401,28 @@ __global__ void k_photon_query(DevPhotonMap G, const uint64_t *meta, const float
     uint32_t found = 0;
     if (G.count) {
         f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);  // photon_tree.rs:16-18
-        uint32_t x0 = cell_coord(lo.x, G.inv_cell), x1 = cell_coord(hi.x, G.inv_cell);
-        uint32_t y0 = cell_coord(lo.y, G.inv_cell), y1 = cell_coord(hi.y, G.inv_cell);
-        uint32_t z0 = cell_coord(lo.z, G.inv_cell), z1 = cell_coord(hi.z, G.inv_cell);
         uint64_t *keys = key_out + (size_t)q * k_max;
         float *d2s = dist2_out + (size_t)q * k_max;
-        for (uint32_t cx = x0; cx <= x1; cx++)
-            for (uint32_t cy = y0; cy <= y1; cy++)
-                for (uint32_t cz = z0; cz <= z1; cz++) {
-                    uint2 range = lookup_cell(G, cell_key(cx, cy, cz));
-                    for (uint32_t i = range.x; i < range.x + range.y && i < G.count; i++) {
-                        float4 c = G.pos_cell[i];
-                        if (!(c.x >= lo.x && c.x <= hi.x && c.y >= lo.y && c.y <= hi.y && c.z >= lo.z && c.z <= hi.z)) continue;
-                        float d2 = lensq3(mk3(c.x, c.y, c.z) - p);  // (photon.position.vector() - position.vector()).len_sqrd()
-                        uint64_t key = meta[i];
-                        uint32_t have = min(found, k_max);
-                        found++;
-                        // insertion into the sorted prefix kept so far (rows are private to the lane)
-                        uint32_t at = have;
-                        while (at > 0 && (d2s[at - 1] > d2 || (d2s[at - 1] == d2 && keys[at - 1] > key))) at--;
-                        if (at >= k_max) continue;
-                        for (uint32_t m = min(have, k_max - 1); m > at; m--) {
-                            d2s[m] = d2s[m - 1];
-                            keys[m] = keys[m - 1];
-                        }
-                        d2s[at] = d2;
-                        keys[at] = key;
-                    }
+        visit_runs(G, lo, hi, [&](uint2 range) {
+            for (uint32_t i = range.x; i < range.x + range.y && i < G.count; i++) {
+                float4 c = G.pos_cell[i];
+                if (!(c.x >= lo.x && c.x <= hi.x && c.y >= lo.y && c.y <= hi.y && c.z >= lo.z && c.z <= hi.z)) continue;
+                float d2 = lensq3(mk3(c.x, c.y, c.z) - p);  // (photon.position.vector() - position.vector()).len_sqrd()
+                uint64_t key = meta[i];
+                uint32_t have = min(found, k_max);
+                found++;
+                // insertion into the sorted prefix kept so far (rows are private to the lane)
+                uint32_t at = have;
+                while (at > 0 && (d2s[at - 1] > d2 || (d2s[at - 1] == d2 && keys[at - 1] > key))) at--;
+                if (at >= k_max) continue;
+                for (uint32_t m = min(have, k_max - 1); m > at; m--) {
+                    d2s[m] = d2s[m - 1];
+                    keys[m] = keys[m - 1];
                 }
+                d2s[at] = d2;
+                keys[at] = key;
+            }
+        });
     }
     count[q] = found;
 }
@@ -469,23 +497,105 @@ static int sort_by_meta(PhotonScratch &W, PhotonBuffers &b) {
     return RRT_OK;
 }
 
+// The dense region.  Photon maps have heavy tails: the reference's infinite planes catch photons (and, behind every
+// landing, shadow photons) thousands of units away, while the queries of a frame fall where the scene is.  The region
+// starts as the box of (all but the outermost 0.2 % per side of) a strided sample of the positions and is trimmed face by
+// face — always the face whose outer 20 % slab holds the fewest samples — until its grid fits the cell budget (4 cells per
+// record, between 2^20 and 2^24 cells): sparse tails go first, from whichever side they are on, the dense core stays.
+// Deterministic in the record set (the records are in canonical order here), and only performance depends on it:
+// records outside the region go to the hash grid.
+static int choose_dense_region(rrt_scene *s, const PhotonBuffers &b, uint32_t n, float cell, PhotonIndex &X) {
+    PhotonScratch &W = s->photon_scratch;
+    const uint32_t n_samples = std::min<uint32_t>(n, 2048), stride = std::max<uint32_t>(1, n / n_samples);
+    int rc = W.t.ensure(n_samples);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sample_positions, grid_for(n_samples), dim3(256), 0, nullptr, b.pos.p, n, stride, n_samples, W.t.p);
+    std::vector<float4> host(n_samples);
+    RRT_HIP(hipMemcpy(host.data(), W.t.p, (size_t)n_samples * sizeof(float4), hipMemcpyDeviceToHost));
+    std::vector<std::array<float, 3>> pts;
+    pts.reserve(n_samples);
+    for (const float4 &p : host)
+        if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) pts.push_back({p.x, p.y, p.z});
+    if (pts.empty()) pts.push_back({0.0f, 0.0f, 0.0f});
+    double lo[3], hi[3];
+    {
+        std::vector<float> v(pts.size());
+        for (int a = 0; a < 3; a++) {
+            for (size_t k = 0; k < pts.size(); k++) v[k] = pts[k][a];
+            std::sort(v.begin(), v.end());
+            const size_t m = v.size() - 1;
+            lo[a] = v[(size_t)(0.002 * (double)m)];
+            hi[a] = v[(size_t)(0.998 * (double)m)];
+        }
+    }
+    const double budget = (double)std::min<uint64_t>(std::max<uint64_t>(4ull * n, 1ull << 20), 1ull << 24);
+    auto cells_of = [&](int a) { return std::max(1.0, std::ceil((hi[a] - lo[a]) / (double)cell) + 4.0); };
+    for (int it = 0; it < 400 && cells_of(0) * cells_of(1) * cells_of(2) > budget; it++) {
+        double cut[6];  // new position of face 2a (low) / 2a + 1 (high)
+        uint32_t loss[6] = {0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < 3; a++) {
+            cut[2 * a] = lo[a] + 0.2 * (hi[a] - lo[a]);
+            cut[2 * a + 1] = hi[a] - 0.2 * (hi[a] - lo[a]);
+        }
+        for (const auto &p : pts) {
+            if (!(p[0] >= lo[0] && p[0] <= hi[0] && p[1] >= lo[1] && p[1] <= hi[1] && p[2] >= lo[2] && p[2] <= hi[2])) continue;
+            for (int a = 0; a < 3; a++) {
+                if (p[a] < cut[2 * a]) loss[2 * a]++;
+                if (p[a] > cut[2 * a + 1]) loss[2 * a + 1]++;
+            }
+        }
+        int best = -1;
+        for (int f = 0; f < 6; f++) {
+            if (cells_of(f / 2) <= 8.0) continue;  // an axis this thin is not what makes the grid large
+            if (best < 0 || loss[f] < loss[best]) best = f;
+        }
+        if (best < 0) break;
+        if (best & 1)
+            hi[best / 2] = cut[best];
+        else
+            lo[best / 2] = cut[best];
+    }
+    double dims[3];
+    for (int a = 0; a < 3; a++) {
+        lo[a] -= 2.0 * (double)cell;
+        dims[a] = cells_of(a);
+    }
+    while (dims[0] * dims[1] * dims[2] > budget) {  // (only if the loop above ran out of iterations)
+        int a = dims[0] >= dims[1] && dims[0] >= dims[2] ? 0 : (dims[1] >= dims[2] ? 1 : 2);
+        dims[a] = std::max(1.0, std::floor(dims[a] / 2.0));
+    }
+    X.dlo[0] = (float)lo[0], X.dlo[1] = (float)lo[1], X.dlo[2] = (float)lo[2];
+    X.nx = (uint32_t)dims[0], X.ny = (uint32_t)dims[1], X.nz = (uint32_t)dims[2];
+    return RRT_OK;
+}
+
 static int build_index(rrt_scene *s, int which) {
     PhotonBuffers &b = s->local[which];
     PhotonIndex &X = s->index[which];
     uint32_t n = (uint32_t)b.count;
+    const float cell = s->params.gather_half_width;
     X.count = n;
-    X.inv_cell = 1.0f / (2.0f * s->params.gather_half_width);
+    X.inv_cell = 1.0f / (2.0f * cell);
+    X.inv_dcell = 1.0f / cell;
     X.table_size = 0;
     X.crowding = 0.0;
+    X.n_dense = 0;
+    X.nx = X.ny = X.nz = 1;
+    X.dlo[0] = X.dlo[1] = X.dlo[2] = 0.0f;
     s->map_view[which] = X.view();
     if (n == 0) return RRT_OK;
+    if (!(cell > 0.0f) || !std::isfinite(X.inv_dcell)) return fail(RRT_ERR_INVALID, "gather_half_width must be positive");
     int rc;
     PhotonScratch &W = s->photon_scratch;
     if ((rc = sort_by_meta(W, b))) return rc;  // canonical order first; the cell sort below is stable
+    if ((rc = choose_dense_region(s, b, n, cell, X))) return rc;
+    const uint32_t cells = X.nx * X.ny * X.nz;
     DBuf<uint64_t> &keys = W.keys, &keys2 = W.keys2;
     DBuf<uint32_t> &idx = W.idx, &idx2 = W.idx2, &ncell = W.ncell;
-    if ((rc = keys.ensure(n)) || (rc = keys2.ensure(n)) || (rc = idx.ensure(n)) || (rc = idx2.ensure(n)) || (rc = ncell.ensure(PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE))) return rc;
-    hipLaunchKernelGGL(k_cell_keys, grid_for(n), dim3(256), 0, nullptr, b.pos.p, n, X.inv_cell, keys.p, idx.p);
+    if ((rc = keys.ensure(std::max<size_t>(n, 512))) || (rc = keys2.ensure(n)) || (rc = idx.ensure(n)) || (rc = idx2.ensure(n)) ||
+        (rc = ncell.ensure(PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE + 1)))
+        return rc;
+    hipLaunchKernelGGL(k_cell_keys, grid_for(n), dim3(256), 0, nullptr, b.pos.p, n, X.view(), keys.p, idx.p);
     if ((rc = sort_pairs(W, keys.p, keys2.p, idx.p, idx2.p, n, nullptr))) return rc;
     if ((rc = X.pos.ensure(n)) || (rc = X.dir.ensure(n)) || (rc = X.rgb.ensure(n))) return rc;
     hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.pos.p, idx2.p, n, X.pos.p);
@@ -493,35 +603,45 @@ static int build_index(rrt_scene *s, int which) {
     hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.rgb.p, idx2.p, n, X.rgb.p);
     if ((rc = X.meta.ensure(n))) return rc;
     hipLaunchKernelGGL(k_gather<uint64_t>, grid_for(n), dim3(256), 0, nullptr, b.meta.p, idx2.p, n, X.meta.p);
+    // dense part: the start table, and where the outliers begin
+    if ((rc = X.dense_start.ensure((size_t)cells + 1))) return rc;
+    uint32_t *n_dense_dev = ncell.p + PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE;
+    hipLaunchKernelGGL(k_dense_starts, grid_for((uint64_t)cells + 1), dim3(256), 0, nullptr, keys2.p, n, cells, X.dense_start.p, n_dense_dev);
+    // outliers: occupied hash cells -> table
     RRT_HIP(hipMemsetAsync(ncell.p, 0, PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE * sizeof(uint32_t), nullptr));
-    hipLaunchKernelGGL(k_count_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, ncell.p);
-    uint32_t cells = 0;
-    {
+    uint32_t n_dense = 0;
+    RRT_HIP(hipMemcpy(&n_dense, n_dense_dev, sizeof(n_dense), hipMemcpyDeviceToHost));
+    if (n_dense > n) return fail(RRT_ERR_DEVICE, "photon index: bad dense record count");
+    X.n_dense = n_dense;
+    const uint32_t n_out = n - n_dense;
+    uint32_t out_cells = 0;
+    if (n_out) {
+        hipLaunchKernelGGL(k_count_cells, grid_for(n_out), dim3(256), 0, nullptr, keys2.p + n_dense, n_out, ncell.p);
         uint32_t part[PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE];
         RRT_HIP(hipMemcpy(part, ncell.p, sizeof(part), hipMemcpyDeviceToHost));
-        for (int k = 0; k < PH_CELL_COUNTERS; k++) cells += part[k * PH_CELL_COUNTER_STRIDE];
+        for (int k = 0; k < PH_CELL_COUNTERS; k++) out_cells += part[k * PH_CELL_COUNTER_STRIDE];
     }
-    if (getenv("RRT_INDEX_INFO")) fprintf(stderr, "[index %d] %u records in %u cells (%.1f per occupied cell)\n", which, n, cells, (double)n / cells);
-    if (cells >= (1u << 30)) return fail(RRT_ERR_LIMIT, "photon index above 2^30 occupied cells");
+    if (out_cells >= (1u << 30)) return fail(RRT_ERR_LIMIT, "photon index above 2^30 occupied outlier cells");
     uint32_t size = 64;
-    while (size < 2 * cells) size <<= 1;
+    while (size < 2 * out_cells) size <<= 1;
     if ((rc = X.keys.ensure(size)) || (rc = X.ranges.ensure(size))) return rc;
     X.table_size = size;
     hipLaunchKernelGGL(k_fill_u64, grid_for(size), dim3(256), 0, nullptr, X.keys.p, size, ~0ULL);
-    hipLaunchKernelGGL(k_insert_cells, grid_for(n), dim3(256), 0, nullptr, keys2.p, n, X.keys.p, X.ranges.p, size - 1);
+    if (n_out) hipLaunchKernelGGL(k_insert_cells, grid_for(n_out), dim3(256), 0, nullptr, keys2.p + n_dense, n_out, n_dense, X.keys.p, X.ranges.p, size - 1);
     RRT_HIP(hipGetLastError());
-    {   // how crowded the cells are where the photons are (sizes the default heavy-query threshold, runtime.cpp)
+    {   // how crowded the cells are where the photons are (sizes the default heavy-query threshold, rrt_photon_build)
         DBuf<uint64_t> &acc = W.keys;  // the unsorted cell keys are no longer needed
-        if ((rc = acc.ensure(512))) return rc;
         RRT_HIP(hipMemsetAsync(acc.p, 0, 512 * sizeof(unsigned long long), nullptr));
-        hipLaunchKernelGGL(k_cell_crowding, grid_for(size), dim3(256), 0, nullptr, X.keys.p, X.ranges.p, size, (unsigned long long *)acc.p);
+        hipLaunchKernelGGL(k_dense_crowding, grid_for(cells), dim3(256), 0, nullptr, X.dense_start.p, cells, (unsigned long long *)acc.p);
         unsigned long long part[512];
         RRT_HIP(hipMemcpy(part, acc.p, sizeof(part), hipMemcpyDeviceToHost));
         unsigned long long sum = 0;
         for (int k = 0; k < 64; k++) sum += part[k * 8];
         X.crowding = (double)sum / (double)n;
-        if (getenv("RRT_INDEX_INFO")) fprintf(stderr, "[index %d] crowding %.1f\n", which, X.crowding);
     }
+    if (getenv("RRT_INDEX_INFO"))
+        fprintf(stderr, "[index %d] %u records: %u in a %u x %u x %u dense grid (cell %.3g, from %.3f %.3f %.3f), %u outliers in %u hash cells; crowding %.1f\n",
+                which, n, n_dense, X.nx, X.ny, X.nz, cell, X.dlo[0], X.dlo[1], X.dlo[2], n_out, out_cells, X.crowding);
     RRT_HIP(hipDeviceSynchronize());
     s->map_view[which] = X.view();
     return RRT_OK;
@@ -720,11 +840,12 @@ int rrt_photon_build(rrt_scene *s) {
     s->stats.ms_photon_build = ms;
     s->stats.photons_stored_regular = s->local[0].count;
     s->stats.photons_stored_caustic = s->local[1].count;
-    // Default heavy-query threshold: a query pair on a lit surface reads about 9 x crowding(regular map) candidate records
-    // (measured on scene2 from 1 M to 100 M photons); queries 4 x heavier than that are the tail of a launch and get a
-    // wave of their own.  A property of the maps, not of the camera: the same frame always takes the same path.
+    // Default heavy-query threshold: a query pair on a lit surface reads about 13 x crowding(regular map) candidate records
+    // (crowding = occupancy of the dense cell, edge r, a random photon lies in; measured on scene2: 148 candidates per pair
+    // at crowding 11); queries 4 x heavier than that are the tail of a launch and get a wave of their own.  A property of
+    // the maps, not of the camera: the same frame always takes the same path.
     {
-        double t = 36.0 * s->index[0].crowding;
+        double t = 52.0 * s->index[0].crowding;
         s->heavy_auto = t > 4.0e9 ? 0xFFFFFFFEu : std::max<uint32_t>(RRT_HEAVY_THRESHOLD, (uint32_t)t);
     }
     s->maps_built = true;

@@ -66,6 +66,11 @@ DevPhotonMap PhotonIndex::view() const {
     m.table_mask = table_size ? table_size - 1 : 0;
     m.count = (uint32_t)count;
     m.inv_cell = inv_cell;
+    m.dense_start = dense_start.p;
+    m.nx = nx, m.ny = ny, m.nz = nz;
+    m.n_dense = n_dense;
+    m.dlo_x = dlo[0], m.dlo_y = dlo[1], m.dlo_z = dlo[2];
+    m.inv_dcell = inv_dcell;
     return m;
 }
 

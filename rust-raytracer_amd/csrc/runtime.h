@@ -87,11 +87,16 @@ struct PhotonBuffers {
 struct PhotonIndex {
     DBuf<float4> pos, dir, rgb;
     DBuf<uint64_t> meta;  // record keys in cell order (only the query entry point reads them)
-    DBuf<uint64_t> keys;
+    DBuf<uint64_t> keys;     // outliers' hash table
     DBuf<uint2> ranges;
+    DBuf<uint32_t> dense_start;  // dense grid: first record of every cell (+ one past the last)
     uint32_t table_size = 0;
     uint64_t count = 0;
-    float inv_cell = 0.0f;
+    float inv_cell = 0.0f;   // hash grid, cell edge 2r
+    float inv_dcell = 0.0f;  // dense grid, cell edge r
+    float dlo[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t nx = 1, ny = 1, nz = 1;
+    uint32_t n_dense = 0;
     double crowding = 0.0;  // sum over cells of count^2 / records: the occupancy of the cell a random photon lies in
     DevPhotonMap view() const;
 };

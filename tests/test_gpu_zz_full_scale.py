@@ -78,3 +78,57 @@ def test_c4_million_triangle_mesh_4k_both_builders_and_oracle_sample(repo):
             assert np.array_equal(bits(g[k]), bits(c[k])), k
     assert np.array_equal(c["object_id"], ids[px[:, 1], px[:, 0]])       # and they are the frame's primary hits
     assert np.array_equal(bits(c["distance"]), bits(depth[px[:, 1], px[:, 0]]))
+
+
+@pytest.mark.parametrize("variant", ["mirror", "glass"])
+def test_c4_secondary_rays_through_the_million_triangle_bvh(repo, variant):
+    """BASELINE configs[3] with reflective / refractive teapots (bench_extra.build_mesh_scene variants): reflection and
+    refraction rays bounce incoherently through the 1 068 080-triangle BVH, five levels deep.  The whole recursion of a
+    sample of the 4K frame's camera rays goes through the oracle (brute force over every triangle for every bounce and
+    shadow ray): object ids and depth bit-exact, RGB within 1/255; and the sample equals the frame's pixels."""
+    import sys
+    import threading
+
+    import numpy as np
+
+    sys.path.insert(0, repo)
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    import bench_extra
+    import oracle_binding as ob
+
+    rrt = ob.rrt
+    bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    gpu, cam, ntri = bench_extra.build_mesh_scene(rrt, variant=variant)
+    gpu.pre_render(1)
+    rgb, depth, ids = gpu.render(cam)
+    st = gpu.stats()
+    assert ntri == 1068080 and st["rays_secondary"] > 2_000_000           # secondary rays really were traced through the BVH
+    assert st["bvh_tris_tested"] > st["rays_primary"]
+    cpu = ob.OracleScene()
+    bench_extra.build_mesh_scene(rrt, variant=variant, scene=cpu)
+    cpu.pre_render(1, threads=1)
+    rng = np.random.default_rng(11)
+    # pixels on teapots (object 0) are the ones that spawn secondary rays: take most of the sample there
+    on_mesh = np.argwhere(ids == 0)
+    pick = on_mesh[rng.choice(len(on_mesh), 72, replace=False)]
+    px = np.concatenate([pick[:, ::-1], np.stack([rng.integers(0, 3840, 24), rng.integers(0, 2160, 24)], axis=1)])
+    rays = [rrt.camera_ray(cam, int(x), int(y)) for x, y in px]
+    o = np.ascontiguousarray([r[0] for r in rays], np.float32)
+    d = np.ascontiguousarray([r[1] for r in rays], np.float32)
+    n_threads = min(8, os.cpu_count() or 1)
+    parts, out = np.array_split(np.arange(len(o)), n_threads), [None] * n_threads
+
+    def work(j):
+        out[j] = cpu.raytrace(o[parts[j]], d[parts[j]])
+
+    th = [threading.Thread(target=work, args=(j,)) for j in range(n_threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    rgb_c, depth_c, id_c = (np.concatenate([p[k] for p in out]) for k in range(3))
+    rgb_g, depth_g, id_g = gpu.raytrace(o, d)
+    assert np.array_equal(id_g, id_c) and np.array_equal(bits(depth_g), bits(depth_c))
+    assert np.abs(rrt.quantise(rgb_g).astype(int) - ob.quantise(rgb_c).astype(int)).max() <= 1
+    assert (bits(rgb_g) == bits(rgb_c)).mean() > 0.9                      # and nearly every f32 value is the same bits
+    assert np.array_equal(id_g, ids[px[:, 1], px[:, 0]]) and np.array_equal(bits(rgb_g), bits(rgb[px[:, 1], px[:, 0]]))
