@@ -21,8 +21,9 @@ The same JSON line carries
                   ("valu_fp32").  `achieved` = algorithmic flops (27 per ray/box and 61 per ray/triangle
                   test the traversal performed + the analytic primitives of every trace) / HIP-event time of the launches
                   on their stream; `peak` 157.3 TFLOP/s counts an FMA as two and packed issue, `frac_no_fma` prices the
-                  same work against the 39.3 TFLOP/s that plain one-flop-per-lane instructions can reach; `traffic` = HBM
-                  bytes per launch from the committed PMC passes (profiles/r02/).
+                  same work against the 39.3 TFLOP/s that plain one-flop-per-lane instructions can reach, `frac_executed`
+                  the lane-operations the vector ALUs really issued (PMC, address arithmetic and selects included) against
+                  that same roof; `traffic` = HBM bytes per launch from the committed PMC passes (profiles/r02/).
   `cpu_baseline`  the CPU oracle (a port of the reference's brute-force loop over every triangle; the Rust binary cannot
                   be built here) on a bounded sample of the same frame's camera rays, min(16, cpus) threads.
   `extra`         N = 1: the other single-GPU configurations (configs[1] CSG scene, configs[2] photon-mapped scene2,
@@ -85,13 +86,14 @@ def cpu_baseline_mesh(rrt, cam, rays_wanted=2304):
     }
 
 
-def measured_traffic():
-    """HBM bytes per k_trace_shade launch of this workload from the committed PMC passes."""
+def measured_counters():
+    """(HBM bytes, VALU lane-operations executed) per k_trace_shade launch of this workload from the committed PMC passes."""
     f = os.path.join(REPO, "profiles/r02/c4_mesh_pmc_traffic.json")
     if not os.path.exists(f):
-        return None
+        return None, None
     with open(f) as fh:
-        return json.load(fh).get("hbm_bytes_per_launch")
+        d = json.load(fh)
+    return d.get("hbm_bytes_per_launch"), d.get("valu_lane_ops_executed_per_launch")
 
 
 def photon_pass_leg(rrt, torch, D, dist, rank, world, device, stage_host, photons_per_rank, width, height, interleave):
@@ -244,7 +246,7 @@ def main():
     if rank == 0:
         # this rank's launches (its share of every frame): flops of the share / HIP-event time of the share's launches
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        traffic = measured_traffic() if world == 1 else None
+        traffic, lane_ops = measured_counters() if world == 1 else (None, None)
         per_launch_ms = kernel_ms / max(1, args.steps)
         gather_bytes = fg.bytes_per_frame()
         out = {
@@ -282,6 +284,10 @@ def main():
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "peak_no_fma": PEAK_FP32_NO_FMA,
                 "frac_no_fma": achieved / PEAK_FP32_NO_FMA,
+                # what the vector ALUs really issued (SQ_THREAD_CYCLES_VALU: active lanes summed over every VALU instruction,
+                # address arithmetic, compares and selects included) against the same one-op-per-lane roof
+                "valu_lane_ops_executed_per_launch": lane_ops,
+                "frac_executed": lane_ops / (per_launch_ms * 1e-3) / 1e12 / PEAK_FP32_NO_FMA if lane_ops and per_launch_ms > 0 else None,
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, corrected as the MI355X guide prescribes; profiles/r02/c4_mesh_pmc_traffic.json)",
                 "hbm_gb_per_s": traffic / (per_launch_ms * 1e-3) / 1e9 if traffic and per_launch_ms > 0 else None,

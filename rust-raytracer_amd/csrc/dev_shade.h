@@ -1,6 +1,7 @@
 // dev_shade.h — materials and lights on the device (src/materials/*.rs, src/lights/*.rs).
 // Parameters come from the host-built tables in dev_scene.h; evaluation happens per lane.
 #pragma once
+#include "dev_pow.h"
 #include "dev_trace.h"
 
 namespace rrt {
@@ -31,8 +32,9 @@ __device__ __forceinline__ f3 phong_diffuse(f3 colour, const HitAttr &h, f3 ldir
 // phong_material.rs:30-34
 __device__ __forceinline__ f3 phong_specular(const HitAttr &h, f3 ldir, f3 viewer, float shininess) {
     f3 refl = norm3(reflect3(h.normal, ldir));
-    // through f64, rounded to f32 once: a correctly rounded powf on both sides of the parity check (see eval_hit)
-    float s = (float)pow((double)fmaxf(dot3(viewer, refl), 0.0f), (double)shininess);
+    // through f64, rounded to f32 once: a correctly rounded powf on both sides of the parity check (see eval_hit);
+    // dev_pow.h says why this is not ocml's pow
+    float s = pow_f32(fmaxf(dot3(viewer, refl), 0.0f), shininess);
     return mk3(1.0f * s, 1.0f * s, 1.0f * s);
 }
 
@@ -54,9 +56,10 @@ __device__ __forceinline__ f3 material_once_pre(const DevScene &S, const DevMate
 __device__ __forceinline__ f3 material_per_light(const DevScene &S, const DevMaterial &M, const HitAttr &h, f3 viewer, f3 ldir,
                                                  Counters &cnt) {
     f3 acc = mk3(0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int i = 0; i < RRT_MAX_COMPOUND_PARTS; i++) {
-        if (i >= M.n_parts) break;
+    // not unrolled: the f64 pow of the specular term is some 300 instructions and three dozen live doubles; four copies of
+    // it pushed the mesh kernels 37 VGPRs over their budget (1.8 GB of scratch writes per 4K frame, profiles/r02)
+#pragma unroll 1
+    for (int i = 0; i < M.n_parts; i++) {
         const MatPart &P = M.parts[i];
         f3 v = mk3(0.0f, 0.0f, 0.0f);
         if (P.kind == RRT_MAT_MONOCHROME || P.kind == RRT_MAT_TEXTURE)

@@ -303,3 +303,15 @@ def test_device_lbvh_functions_pass_the_cpu_preflight(repo, tmp_path):
                            os.path.join(repo, "tools/cpu_emu/lbvh_check.cpp")])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_device_pow_rounds_like_the_oracle_pow(repo, tmp_path):
+    """rrt::pow_f32 (csrc/dev_pow.h, the specular power on the device) against the f64 std::pow rounded once to f32 — what
+    the oracle computes — on 3 M (base, shininess) pairs and IEEE pow's special cases, bit for bit."""
+    import subprocess
+
+    exe = tmp_path / "pow_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(repo, "tools/cpu_emu"),
+                           "-I" + os.path.join(repo, "rust-raytracer_amd/csrc"), "-o", str(exe), os.path.join(repo, "tools/cpu_emu/pow_check.cpp")])
+    out = subprocess.run([str(exe), "3000000"], capture_output=True, text=True)
+    assert out.returncode == 0 and "differ-in-last-bit 0 " in out.stdout and "special-cases-wrong 0" in out.stdout, out.stdout[-2000:]

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 2 evidence in one GPU call: kernel statistics and the PMC passes of the bench's own command (configs[3], mesh)
+# and of the photon leg (configs[2]).  usage (GPU box, repo root): tools/r2_profile_all.sh
+set -u
+root=$PWD
+out=$root/gpurun_out/r02
+mkdir -p "$out"
+bench="python3 $root/bench.py --no-extra --no-cpu-baseline --steps 20 --warmup 3"
+photon="python3 $root/bench_extra.py photon"
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/c4_stats" -o c4 -- $bench > "$out/c4_stats.json.log" 2>&1 ) || { tail -5 "$out/c4_stats.json.log"; exit 1; }
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/c3_stats" -o c3 -- $photon > "$out/c3_stats.json.log" 2>&1 ) || { tail -5 "$out/c3_stats.json.log"; exit 1; }
+tools/pmc_passes.sh r02_c4 -- $bench || exit 1
+tools/pmc_passes.sh r02_c3 -- $photon || exit 1
+tools/pmc_mem_passes.sh r02_c4_mem -- $bench || exit 1
+for f in "$out"/c4_stats/*kernel_stats.csv "$out"/c3_stats/*kernel_stats.csv; do echo "== $f"; head -5 "$f" | cut -c1-160; done
