@@ -66,8 +66,15 @@ typedef struct rrt_params {
                                            its lane.  0 = default: derived from the photon maps at rrt_photon_build (4 x the
                                            candidate records of a typical query, at least 2048); 0xFFFFFFFF = never.  Same
                                            photons; the f32 sums are added in another (fixed) order                     */
-    uint32_t reserved[6];
+    uint32_t gather_k;                  /* photon mode: 0 (default) = the reference's estimator, every photon inside the cube
+                                           (photon_scene.rs:393 get_within_distance); k > 0 = PhotonTree::get_n_within_radius
+                                           (photon_tree.rs:41-50, written but never called by the reference) as the estimator:
+                                           the k photons of the cube closest to the hit (ascending squared distance, ties by
+                                           record key), summed in that order.  At most RRT_GATHER_K_MAX; needs 8 k bytes of
+                                           device workspace per ray in flight (chunks shrink to keep that under 2 GiB)      */
+    uint32_t reserved[5];
 } rrt_params;
+#define RRT_GATHER_K_MAX 4096
 enum rrt_bvh_builder { RRT_BVH_HOST_SAH = 0, RRT_BVH_DEVICE_LBVH = 1 };
 
 /* ---- materials (src/materials) ------------------------------------------------------ */

@@ -898,8 +898,10 @@ struct Env {
         stats.photons_gathered.fetch_add(found.size(), std::memory_order_relaxed);
         V3 p = hit.position;
         std::sort(found.begin(), found.end(), [p](const Photon *a, const Photon *b) {  // photon_tree.rs:33
-            return len_sqrd(a->position - p) < len_sqrd(b->position - p);
+            float da = len_sqrd(a->position - p), db = len_sqrd(b->position - p);
+            return da != db ? da < db : a->key < b->key;  // the reference's sort is unstable on ties: by key, to be deterministic
         });
+        if (params.gather_k && found.size() > params.gather_k) found.resize(params.gather_k);  // get_n_within_radius: truncate(n), photon_tree.rs:41-50
         float n = (float)found.size();
         V3 ldir{0, 0, 0};
         Colour inten = black();

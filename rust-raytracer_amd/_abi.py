@@ -10,6 +10,7 @@ CSG_UNION, CSG_INTERSECTION, CSG_DIFFERENCE = range(3)
 LIGHT_DIRECTIONAL, LIGHT_POINT, LIGHT_DIRPOINT = range(3)
 MISS = 0xFFFFFFFF
 NOALLOC_MAX_RAYS = 65536  # RRT_NOALLOC_MAX_RAYS
+GATHER_K_MAX = 4096  # RRT_GATHER_K_MAX
 
 
 BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
@@ -27,7 +28,8 @@ class Params(C.Structure):
         ("render_streams", C.c_uint32),
         ("bvh_builder", C.c_uint32),
         ("gather_heavy_threshold", C.c_uint32),
-        ("reserved", C.c_uint32 * 6),
+        ("gather_k", C.c_uint32),
+        ("reserved", C.c_uint32 * 5),
     ]
 
 

@@ -83,8 +83,9 @@ RRT_HD uint32_t hash_key(uint64_t k) {
 struct GatherSums {
     f3 ldir;       // sum of normalised incidents
     f3 intensity;  // sum of intensities
-    uint32_t k;    // photons inside the closed box
+    uint32_t k;    // photons summed: those inside the closed box, or the nearest gather_k of them
     uint32_t candidates;
+    uint32_t inside;  // gather_knn only: photons inside the closed box before the truncation to k
 };
 
 // ---- the index: a dense grid where the photons are, a hash grid for the stragglers ---------------------------------
@@ -226,6 +227,93 @@ __device__ __forceinline__ void stream_cells(const DevPhotonMap &G, const CellSe
     for (uint32_t c = 0; c < 9; c++) stream_cell(G, C.rg[c], lo, hi, s);
 }
 
+// ---- PhotonTree::get_n_within_radius (photon_tree.rs:41-50) as the estimator ------------------------------------------
+// get_within_distance sorted by squared distance, truncated to the first k: the k photons of the cube closest to the hit.
+// The lane keeps the k best (squared distance, record index) pairs seen so far in a max-heap in its column of the
+// workspace (entry e at ws[e * stride]: neighbouring lanes touch neighbouring words), replaces the root whenever a closer
+// photon turns up, heap-sorts the column in place at the end and adds the photons in ascending order — the order the
+// reference's loop meets them in (photon_scene.rs:404-407), so the f32 sums are the reference's, bit for bit.
+struct KnnColumn {
+    uint2 *ws;
+    uint32_t stride;
+    __device__ __forceinline__ uint2 get(uint32_t e) const { return ws[(size_t)e * stride]; }
+    __device__ __forceinline__ void put(uint32_t e, uint2 v) const { ws[(size_t)e * stride] = v; }
+};
+// does a come before b?  Squared distance first; equal distances by record key (the reference's sort_unstable leaves
+// that order open, the oracle fixes it the same way)
+__device__ __forceinline__ bool knn_before(const DevPhotonMap &G, uint2 a, uint2 b) {
+    const float da = __uint_as_float(a.x), db = __uint_as_float(b.x);
+    if (da != db) return da < db;
+    return G.meta[a.y] < G.meta[b.y];
+}
+// put `item` where the root was and let it sink (heap of n entries, largest at the root)
+__device__ __forceinline__ void knn_sift_down(const DevPhotonMap &G, const KnnColumn &H, uint32_t n, uint2 item) {
+    uint32_t e = 0;
+    for (;;) {
+        uint32_t c = 2u * e + 1u;
+        if (c >= n) break;
+        uint2 child = H.get(c);
+        if (c + 1u < n) {
+            const uint2 other = H.get(c + 1u);
+            if (knn_before(G, child, other)) {
+                child = other;
+                c++;
+            }
+        }
+        if (!knn_before(G, item, child)) break;
+        H.put(e, child);
+        e = c;
+    }
+    H.put(e, item);
+}
+__device__ __forceinline__ void gather_knn(const DevPhotonMap &G, f3 p, float r, uint32_t k, const KnnColumn &H, GatherSums &s) {
+    s.ldir = mk3(0.0f, 0.0f, 0.0f);
+    s.intensity = mk3(0.0f, 0.0f, 0.0f);
+    s.k = 0;
+    s.candidates = 0;
+    const f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);  // photon_tree.rs:16-18
+    uint32_t n = 0, inside = 0, candidates = 0;
+    visit_runs(G, lo, hi, [&](uint2 run) {
+        candidates += run.y;
+        uint32_t i = min(run.x, G.count);
+        const uint32_t end = i + min(run.y, G.count - i);  // guard: stay inside the map
+        for (; i < end; i++) {
+            const float4 q = G.pos_cell[i];
+            if (!(q.x >= lo.x && q.x <= hi.x && q.y >= lo.y && q.y <= hi.y && q.z >= lo.z && q.z <= hi.z)) continue;
+            inside++;
+            const uint2 item = make_uint2(__float_as_uint(lensq3(mk3(q.x, q.y, q.z) - p)), i);  // photon_tree.rs:25
+            if (n < k) {  // room left: append and let it rise
+                uint32_t e = n++;
+                while (e > 0) {
+                    const uint32_t parent = (e - 1u) >> 1;
+                    const uint2 up = H.get(parent);
+                    if (!knn_before(G, up, item)) break;
+                    H.put(e, up);
+                    e = parent;
+                }
+                H.put(e, item);
+            } else if (knn_before(G, item, H.get(0))) {  // closer than the farthest kept: replace it
+                knn_sift_down(G, H, n, item);
+            }
+        }
+    });
+    // heap sort in place: the farthest goes to the end, the rest is a heap again
+    for (uint32_t m = n; m > 1; m--) {
+        const uint2 last = H.get(m - 1u);
+        H.put(m - 1u, H.get(0));
+        knn_sift_down(G, H, m - 1u, last);
+    }
+    for (uint32_t e = 0; e < n; e++) {  // photon_scene.rs:404-407, nearest first
+        const uint32_t i = H.get(e).y;
+        const float4 d = G.incident[i], c = G.intensity[i];
+        s.ldir = s.ldir + mk3(d.x, d.y, d.z);
+        s.intensity = s.intensity + mk3(c.x, c.y, c.z);
+    }
+    s.k = n;               // neighbour_photons.len() after truncate(n)
+    s.candidates = candidates;
+    s.inside = inside;
+}
+
 // the blend of average_photon_at (photon_scene.rs:363-420) from the two maps' sums
 __device__ __forceinline__ bool blend_estimates(const GatherSums &reg, const GatherSums &cau, f3 &incident, f3 &intensity) {
     float nr = (float)reg.k, nc = (float)cau.k;
@@ -251,8 +339,16 @@ __device__ __forceinline__ bool blend_estimates(const GatherSums &reg, const Gat
 // Returns 0: no photons, 1: estimate in (incident, intensity), 2: DEFERRED -- the two boxes hold more than `defer_above`
 // candidate records, nothing was read, the caller files the query for k_gather_heavy (pass 0xFFFFFFFF to never defer).
 __device__ __forceinline__ int average_photon_at(const DevPhotonMap maps[2], f3 p, float r, uint32_t defer_above, f3 &incident, f3 &intensity,
-                                                 unsigned long long &gathered, unsigned long long &candidates) {
+                                                 unsigned long long &gathered, unsigned long long &candidates, uint32_t knn_k = 0,
+                                                 KnnColumn knn = KnnColumn{nullptr, 0}) {
     GatherSums reg, cau;
+    if (knn_k) {  // get_n_within_radius instead of get_within_distance; the column is reused by the second map
+        gather_knn(maps[0], p, r, knn_k, knn, reg);
+        gather_knn(maps[1], p, r, knn_k, knn, cau);
+        gathered += reg.inside + cau.inside;
+        candidates += reg.candidates + cau.candidates;
+        return blend_estimates(reg, cau, incident, intensity) ? 1 : 0;
+    }
     f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);  // photon_tree.rs:16-18
     CellSet c0, c1;
     if (lookup_cells(maps[0], lo, hi, c0) && lookup_cells(maps[1], lo, hi, c1)) {

@@ -31,6 +31,7 @@ struct DevPhotonMap {
     uint32_t n_dense;        // records [0, n_dense) lie in dense cells, [n_dense, count) are outliers
     float dlo_x, dlo_y, dlo_z;
     float inv_dcell;         // 1 / half_width
+    const uint64_t *meta;    // [n] record keys (cell order): ties between equal squared distances (k-nearest estimator, queries)
 };
 
 // error bits of TraceArgs::err (1, 2, 4: dev_shade.h)
@@ -80,6 +81,11 @@ struct TraceArgs {
     uint32_t heavy_capacity;   // records the queue holds (the chunk size: every query of a level may be heavy)
     uint32_t *heavy_count;     // this level's counter
     uint32_t heavy_threshold;  // candidate records (both maps) above which a query is filed
+    // PhotonTree::get_n_within_radius as the estimator (rrt_params.gather_k > 0): a heap of knn_k (distance, record) pairs
+    // per ray of the launch, entry e of ray i at knn_ws[e * knn_stride + i]
+    uint32_t knn_k;
+    uint32_t knn_stride;
+    uint2 *knn_ws;
     // level-0 outputs of the combine pass (any may be null)
     float *out_rgb;
     float *out_depth;

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
                     f3 inc, inten;
                     queries += 2;
                     const int got = average_photon_at(A.maps, h.position, A.gather_half_width, A.heavy ? A.heavy_threshold : 0xFFFFFFFFu, inc,
-                                                      inten, gathered, candidates);
+                                                      inten, gathered, candidates, A.knn_k, KnnColumn{A.knn_ws + i, A.knn_stride});
                     if (got == 1) surface = material_render_vueon(S, M, h, inc, inten, -d, cnt);
                     defer = got == 2;  // `once` is written by k_gather_heavy (or below, if the queue is full)
                 }

@@ -71,6 +71,7 @@ DevPhotonMap PhotonIndex::view() const {
     m.n_dense = n_dense;
     m.dlo_x = dlo[0], m.dlo_y = dlo[1], m.dlo_z = dlo[2];
     m.inv_dcell = inv_dcell;
+    m.meta = meta.p;
     return m;
 }
 
@@ -634,6 +635,11 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     uint32_t want_lanes = s->params.render_streams ? std::min(s->params.render_streams, 8u) : 1u;
     if (n_levels == 1) want_lanes = 1;  // no deep levels to hide
     uint32_t chunk = s->params.chunk_pixels ? s->params.chunk_pixels : (1u << 23);  // a 3840x2160 frame is one chunk
+    // photon mode with the k-nearest estimator (get_n_within_radius): every ray in flight owns gather_k heap entries of 8
+    // bytes; chunks shrink so that a level of chunk size stays under 2 GiB of them
+    const uint32_t knn_k = s->mode == RRT_MODE_PHOTON ? s->params.gather_k : 0u;
+    if (knn_k > RRT_GATHER_K_MAX) return fail(RRT_ERR_LIMIT, "gather_k above RRT_GATHER_K_MAX (4096)");
+    if (knn_k) chunk = std::min(chunk, std::max(1u << 16, ((1u << 28) / knn_k) & ~255u));
     if (want_lanes > 1 && n_pixels >= (1u << 18)) {  // big enough to be worth cutting: one chunk per lane, whole waves
         uint32_t per_lane = (n_pixels + want_lanes - 1) / want_lanes;
         per_lane = (per_lane + 255u) & ~255u;
@@ -645,13 +651,15 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     for (uint32_t j = 0; j < want_lanes; j++)
         if (s->lanes[j]->levels.size() < n_levels + 1) s->lanes[j]->levels.resize(n_levels + 1);
     // photon mode: heavy radiance estimates are filed per level (lane counters [32 + level]) and gathered by whole waves
-    const bool heavy_queue = s->mode == RRT_MODE_PHOTON && s->params.gather_heavy_threshold != 0xFFFFFFFFu && n_levels <= 30;
+    const bool heavy_queue = s->mode == RRT_MODE_PHOTON && s->params.gather_heavy_threshold != 0xFFFFFFFFu && n_levels <= 30 && !knn_k;
     // The queue of a level holds one record per ray of that level (every query may be heavy), so it is sized from the
     // level sizes below, never from the chunk: a level behind glass can hold more rays than the chunk has pixels, and a
     // lane that found the queue full would gather for itself in another summation order (frames would then depend on
     // atomics order).
     if (!heavy_queue)
         for (uint32_t j = 0; j < want_lanes; j++) s->lanes[j]->heavy.release();
+    if (!knn_k)
+        for (uint32_t j = 0; j < want_lanes; j++) s->lanes[j]->knn.release();
 
     RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, (RRT_STAT_WORDS + 32) * sizeof(unsigned long long), stream));  // + lane 0's counters
     bool lane0_clean = true;
@@ -710,6 +718,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                 }
                 if ((rc = L.levels[n_run].ensure(1, n_lights, true))) return rc;
                 if (heavy_queue && (rc = L.heavy.ensure(*std::max_element(caps.begin(), caps.end())))) return rc;
+                if (knn_k && (rc = L.knn.ensure((size_t)knn_k * *std::max_element(caps.begin(), caps.end())))) return rc;
                 if (!(j == 0 && lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), st));
                 if (j == 0) lane0_clean = false;
                 if (!cam)
@@ -727,6 +736,9 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                     A.next_count = L.ctr + (k + 1);
                     A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
                     A.heavy_capacity = caps[k];
+                    A.knn_k = knn_k;
+                    A.knn_ws = L.knn.p;
+                    A.knn_stride = caps[k];
                     launch_trace_shade(A, D.lds_bytes, st);
                     launch_gather_heavy(A, st);
                 }
@@ -794,6 +806,12 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
                         if ((rc = L.heavy.ensure(counts[k]))) return rc;
                         A.heavy = L.heavy.p;
                         A.heavy_capacity = counts[k];
+                    }
+                    if (knn_k) {  // same here
+                        if ((rc = L.knn.ensure((size_t)knn_k * counts[k]))) return rc;
+                        A.knn_k = knn_k;
+                        A.knn_ws = L.knn.p;
+                        A.knn_stride = counts[k];
                     }
                     A.cur = L.levels[k].view();
                     A.next = L.levels[k + 1].view();
@@ -1058,6 +1076,7 @@ int rrt_scene_set_params(rrt_scene *s, const rrt_params *params) {
     if (!s || !params) return fail(RRT_ERR_INVALID, "null argument");
     if (params->max_depth > 40 || params->max_vueon_depth > 40 || params->max_photon_bounces > 64)
         return fail(RRT_ERR_LIMIT, "max_depth/max_vueon_depth <= 40, max_photon_bounces <= 64");
+    if (params->gather_k > RRT_GATHER_K_MAX) return fail(RRT_ERR_LIMIT, "gather_k above RRT_GATHER_K_MAX (4096)");
     drop_render_workers(s);  // see rrt_scene_set_mode
     s->params = *params;
     s->maps_built = false;

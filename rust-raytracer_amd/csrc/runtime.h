@@ -86,7 +86,7 @@ struct PhotonBuffers {
 };
 struct PhotonIndex {
     DBuf<float4> pos, dir, rgb;
-    DBuf<uint64_t> meta;  // record keys in cell order (only the query entry point reads them)
+    DBuf<uint64_t> meta;  // record keys in cell order (the query entry points and the k-nearest estimator break ties by them)
     DBuf<uint64_t> keys;     // outliers' hash table
     DBuf<uint2> ranges;
     DBuf<uint32_t> dense_start;  // dense grid: first record of every cell (+ one past the last)
@@ -130,6 +130,7 @@ struct RenderLane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_trace0 = nullptr, ev_trace1 = nullptr, ev_done = nullptr;
     DBuf<HeavyRec> heavy;  // photon mode: the queries of the current level filed for k_gather_heavy
+    DBuf<uint2> knn;       // photon mode with rrt_params.gather_k: gather_k heap entries per ray of the widest level
     // per round of chunks of a frame (a frame larger than the chunk size takes several rounds, each over another part of
     // the image): [0] = chunk size it was measured on, [1 + k] = size of level k
     std::vector<std::vector<uint32_t>> prediction;

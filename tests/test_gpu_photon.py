@@ -86,6 +86,43 @@ def test_heavy_radiance_estimates_gathered_by_whole_waves(repo):
     assert not np.array_equal(bits(low.render(cam)[0]), bits(f_off[0]))        # the other order really was used
 
 
+@pytest.mark.parametrize("name,photons,caustic,k", [("pm_caustics", 60000, 4000, 4), ("scene2", 120000, 5000, 8), ("pm_caustics", 60000, 4000, 1)])
+def test_k_nearest_estimator_matches_get_n_within_radius(repo, name, photons, caustic, k):
+    """rrt_params.gather_k: PhotonTree::get_n_within_radius (photon_tree.rs:41-50) as the radiance estimator of the vueon
+    pass — the k photons of the cube nearest to the hit, added nearest first.  The device keeps them in a per-ray heap and
+    adds them in the reference's order, so against the oracle (which sorts and truncates like the reference) the frame
+    is not only within a quantum: the f32 values are the same bits."""
+    cpu, gpu, cam = pair(repo, name, photons, caustic, gather_k=k)
+    _, every, _ = pair(repo, name, photons, caustic)
+    for s in (cpu, gpu, every):
+        s.pre_render(11)
+    cam.width, cam.height = 176, 128
+    rgb_c, depth_c, id_c = cpu.render(cam)
+    rgb_g, depth_g, id_g = gpu.render(cam)
+    assert np.array_equal(id_c, id_g) and np.array_equal(bits(depth_c), bits(depth_g))
+    dq = np.abs(ob.quantise(rgb_c).astype(int) - rrt.quantise(rgb_g).astype(int))
+    same = (bits(rgb_c) == bits(rgb_g)).mean()
+    assert dq.max() == 0 and same == 1.0, (dq.max(), same)
+    sg, sc = gpu.stats(), cpu.stats()
+    assert sg["photons_gathered"] == sc["photons_gathered"] and sg["gather_queries"] == sc["gather_queries"]
+    assert sg["rays_secondary"] == sc["rays_secondary"]
+    # the truncation really happened: the frame differs from the all-photons estimate
+    rgb_e = every.render(cam)[0]
+    assert np.abs(rrt.quantise(rgb_e).astype(int) - rrt.quantise(rgb_g).astype(int)).max() > 2
+    # bands and repeated calls: same bits (the heap columns belong to rays, not to lanes)
+    top, bottom = gpu.render(cam, 0, 56), gpu.render(cam, 56, cam.height)
+    assert np.array_equal(bits(rgb_g), bits(np.concatenate([top[0], bottom[0]])))
+    assert np.array_equal(bits(rgb_g), bits(gpu.render(cam)[0]))
+
+
+def test_gather_k_limits(repo):
+    params = rrt.default_params(gather_k=abi.GATHER_K_MAX + 1)
+    s, cam = rrt.Scene.load(os.path.join(repo, "assets/scenes/pm_caustics.txt"), mode_override=abi.MODE_PHOTON)
+    with pytest.raises(rrt.RrtError) as e:
+        s.set_params(params)
+    assert e.value.code == abi.ERR_LIMIT and "gather_k" in e.value.message
+
+
 def test_photon_pass_is_deterministic_and_split_independent(repo):
     _, a, cam = pair(repo, "pm_caustics", 30000, 2000)
     _, b, _ = pair(repo, "pm_caustics", 30000, 2000)

@@ -392,3 +392,20 @@ def test_photon_pass_is_independent_of_the_split(repo):
     st = a.stats()
     kc, _, _ = a.photon_query(1, pos, 0.1)
     assert st["photons_gathered"] == k + kc
+
+
+def test_gather_k_is_get_n_within_radius(repo):
+    """rrt_params.gather_k in the oracle: the sorted list of get_within_distance truncated to k (photon_tree.rs:41-50).  A k
+    no cube reaches changes nothing; k = 1 changes the frame but not the number of photons found in the cubes."""
+    path = os.path.join(repo, "assets/scenes/pm_caustics.txt")
+    frames = {}
+    for k in (0, 4096, 1):
+        params = ob.rrt.default_params(photons_per_light=20000, caustic_photons_per_light=1500, gather_k=k)
+        s, cam = ob.OracleScene.load(path, params=params, mode_override=abi.MODE_PHOTON)
+        s.pre_render(3)
+        cam.width, cam.height = 64, 48
+        frames[k] = (s, s.render(cam)[0])
+    assert np.array_equal(frames[0][1].view(np.uint32), frames[4096][1].view(np.uint32))
+    assert not np.array_equal(frames[0][1].view(np.uint32), frames[1][1].view(np.uint32))
+    # every query of the k = 1 frame used at most one photon per map; the statistics still count the cube's photons
+    assert frames[1][0].stats()["photons_gathered"] == frames[0][0].stats()["photons_gathered"]
