@@ -315,3 +315,34 @@ def test_device_pow_rounds_like_the_oracle_pow(repo, tmp_path):
                            "-I" + os.path.join(repo, "rust-raytracer_amd/csrc"), "-o", str(exe), os.path.join(repo, "tools/cpu_emu/pow_check.cpp")])
     out = subprocess.run([str(exe), "3000000"], capture_output=True, text=True)
     assert out.returncode == 0 and "differ-in-last-bit 0 " in out.stdout and "special-cases-wrong 0" in out.stdout, out.stdout[-2000:]
+
+
+def test_rust_bindings_cover_the_header(repo):
+    """integration/rrt-sys/src/lib.rs (shipped uncompiled: no Rust toolchain in the image) against include/rrt.h: every
+    function of the header is declared, no other, and every struct has the header's fields in the header's order."""
+    hdr = open(os.path.join(repo, "include/rrt.h")).read()
+    rs = open(os.path.join(repo, "integration/rrt-sys/src/lib.rs")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    c_funcs = re.findall(r"\b(rrt_[a-z0-9_]+)\s*\(", hdr_nc)
+    rs_funcs = re.findall(r"pub fn (rrt_[a-z0-9_]+)\s*\(", rs)
+    assert sorted(set(c_funcs)) == sorted(set(rs_funcs)), set(c_funcs) ^ set(rs_funcs)
+    assert len(rs_funcs) == len(set(rs_funcs))
+    for name in ("rrt_params", "rrt_material_desc", "rrt_object_desc", "rrt_light_desc", "rrt_camera", "rrt_stats", "rrt_builder"):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr_nc, re.S).group(1)
+        c_fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            fp = re.match(r".*\(\*(\w+)\)\(", decl, re.S)                  # function pointer member
+            if fp:
+                c_fields.append(fp.group(1))
+                continue
+            for part in decl.split(","):                                       # `uint32_t width, height`
+                c_fields.append(re.search(r"(\w+)\s*(\[[^\]]*\])?\s*$", part.strip()).group(1))
+        rbody = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, re.S).group(1)
+        r_fields = re.findall(r"pub (\w+):", rbody)
+        assert c_fields == r_fields, (name, c_fields, r_fields)
+    # constants that size arrays
+    assert "RRT_MAX_COMPOUND_PARTS: usize = 4" in rs and "#define RRT_MAX_COMPOUND_PARTS 4" in hdr
+    assert "RRT_NOALLOC_MAX_RAYS: usize = 65536" in rs and "RRT_GATHER_K_MAX: u32 = 4096" in rs
