@@ -14,8 +14,17 @@
 //      boxes, so the box of ANY sorted range is the union of two entries.  No bottom-up pass, no atomics, no fences:
 //      every node's child boxes are pure functions of its range.                      lbvh::table_level, range_box
 //   6. node emit: ranges of <= 4 triangles become leaves                              lbvh::emit_node
-//   7. host: one DFS that VALIDATES the tree (every node reached once, every triangle slot in exactly one leaf, indices
-//      in range), measures its depth and compacts it into DFS order.  An invalid tree is an error, never traversed.
+//   7. VALIDATION on the device, without a traversal (lbvh::check_node, check_slot, check_order): the sorted order is a
+//      permutation; the root covers [0, n - 1]; every emitted node splits its range into two non-empty parts, an inner
+//      child's own range is exactly the part it is given, and every triangle slot is claimed by exactly one leaf.  Together
+//      these say what a DFS would: starting from the root the ranges nest (induction over the local rule), so every
+//      reachable node is reached once and the reachable leaves cover [0, n - 1] exactly; an emitted node that is NOT
+//      reachable would still end in leaves, which would claim slots a second time.  Anything else raises an error word:
+//      an invalid tree is an error, never traversed.
+//   8. depth of every emitted node by walking the parent links check_node wrote (lbvh::node_depth), its maximum;
+//      compaction by a prefix sum over the emitted flags (Karras order is kept: a node's index is a position in the
+//      Morton order, so neighbours in memory are neighbours in space), child indices renumbered (lbvh::compact_node).
+//      The host's one-DFS version of 7 + 8 (lbvh::finish) stays for the CPU preflight, which checks both against each other.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -192,6 +201,85 @@ LBVH_HD BvhNode emit_node(const Range *ranges, const Box6 *table, uint32_t n, ui
     nd.lo_x_hi_x = make_float4(bx[0].lo[0], bx[1].lo[0], bx[0].hi[0], bx[1].hi[0]);
     nd.lo_y_hi_y = make_float4(bx[0].lo[1], bx[1].lo[1], bx[0].hi[1], bx[1].hi[1]);
     nd.lo_z_hi_z = make_float4(bx[0].lo[2], bx[1].lo[2], bx[0].hi[2], bx[1].hi[2]);
+    return nd;
+}
+
+// ---- 7 + 8 on the device --------------------------------------------------------------------------------------------
+enum : uint32_t {
+    kErrOrder = 1u,     // the sorted order is not a permutation of the triangles
+    kErrRoot = 2u,      // the root does not cover [0, n - 1]
+    kErrSplit = 4u,     // a split outside its node's range
+    kErrChild = 8u,     // an inner child whose own range is not the part it was given (or whose index is out of range)
+    kErrCover = 16u,    // a triangle slot in two leaves, or in none
+    kErrDepth = 32u,    // parent links do not lead to the root within 4096 steps
+};
+LBVH_HD bool is_emitted(const Range &r, uint32_t i) { return i == 0 || r.last - r.first + 1 > kLeafMax; }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LBVH_FETCH_ADD(p, v) atomicAdd((p), (v))
+#define LBVH_FETCH_OR(p, v) atomicOr((p), (v))
+#else  // the CPU preflight runs the same functions one thread after the other
+LBVH_HD uint32_t lbvh_host_add(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+LBVH_HD uint32_t lbvh_host_or(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+#define LBVH_FETCH_ADD(p, v) rrt::lbvh::lbvh_host_add((p), (v))
+#define LBVH_FETCH_OR(p, v) rrt::lbvh::lbvh_host_or((p), (v))
+#endif
+
+// sorted slot i: order[i] must be a triangle nobody else names (seen[] starts at zero)
+LBVH_HD void check_order(const uint32_t *order, uint32_t n, uint32_t i, uint32_t *seen, uint32_t *err) {
+    const uint32_t t = order[i];
+    if (t >= n || LBVH_FETCH_ADD(&seen[t], 1u) != 0u) LBVH_FETCH_OR(err, (uint32_t)kErrOrder);
+}
+// node i (Karras numbering): the local rule of step 7; claims the slots of its leaf children in covered[] (starts at
+// zero) and writes parent[] of its inner children.  Returns whether the node is emitted.
+LBVH_HD bool check_node(const Range *ranges, uint32_t n, uint32_t i, uint32_t *covered, uint32_t *parent, uint32_t *err) {
+    const Range r = ranges[i];
+    if (!(r.first <= r.last && r.last < n)) {  // nothing below can be trusted
+        LBVH_FETCH_OR(err, (uint32_t)kErrSplit);
+        return false;
+    }
+    if (!is_emitted(r, i)) return false;
+    if (i == 0 && !(r.first == 0 && r.last == n - 1)) LBVH_FETCH_OR(err, (uint32_t)kErrRoot);
+    if (!(r.split >= r.first && r.split < r.last)) {
+        LBVH_FETCH_OR(err, (uint32_t)kErrSplit);
+        return true;
+    }
+    for (int c = 0; c < 2; c++) {
+        const uint32_t a = c == 0 ? r.first : r.split + 1, b = c == 0 ? r.split : r.last;
+        if (b - a + 1 <= kLeafMax) {
+            for (uint32_t k = a; k <= b; k++)
+                if (LBVH_FETCH_ADD(&covered[k], 1u) != 0u) LBVH_FETCH_OR(err, (uint32_t)kErrCover);
+        } else {
+            const uint32_t ci = c == 0 ? r.split : r.split + 1;  // what emit_node writes
+            if (ci >= n - 1 || ranges[ci].first != a || ranges[ci].last != b)
+                LBVH_FETCH_OR(err, (uint32_t)kErrChild);
+            else
+                parent[ci] = i;
+        }
+    }
+    return true;
+}
+LBVH_HD void check_slot(const uint32_t *covered, uint32_t i, uint32_t *err) {
+    if (covered[i] != 1u) LBVH_FETCH_OR(err, (uint32_t)kErrCover);
+}
+// depth of emitted node i the way bvh_build.cpp counts (root = 1); 0 when the links do not reach the root
+LBVH_HD uint32_t node_depth(const uint32_t *parent, uint32_t n, uint32_t i, uint32_t *err) {
+    uint32_t d = 1, j = i;
+    while (j != 0) {
+        j = parent[j];
+        d++;
+        if (j >= n - 1 || d > 4096) {
+            LBVH_FETCH_OR(err, (uint32_t)kErrDepth);
+            return 0;
+        }
+    }
+    return d;
+}
+// emitted node i -> its place in the compacted array (new_index = exclusive prefix sum of the emitted flags)
+LBVH_HD BvhNode compact_node(const BvhNode *raw, const uint32_t *new_index, uint32_t i) {
+    BvhNode nd = raw[i];
+    for (int c = 0; c < 2; c++)
+        if (nd.child[c] >= 0) nd.child[c] = (int32_t)new_index[nd.child[c]];
     return nd;
 }
 

@@ -3,7 +3,10 @@
 //   * lbvh::finish accepts the tree (every node reached once, every triangle slot in exactly one leaf, indices in range);
 //   * every leaf box contains its triangles and every child box contains the boxes below it (so traversal can only
 //     prune what it may prune), against boxes recomputed here from the positions;
-//   * the compacted tree's depth is what finish reports.
+//   * the compacted tree's depth is what finish reports;
+//   * the device's own validation (check_order / check_node / check_slot), depth (node_depth) and compaction
+//     (compact_node) accept the same tree, report the same depth and node count, give the same tree node for node, and
+//     refuse damaged ranges and orders.
 // Inputs: random soups, degenerate sets (all triangles identical, coplanar grids, NaN vertices, huge coordinates), sizes
 // 5 .. 200 000, and optionally an OBJ-free raw float file of positions.   usage: lbvh_check [positions.f32]
 #include <stdio.h>
@@ -107,6 +110,66 @@ static int check(const char *name, const std::vector<float> &pos) {
     if (leaf_tris != n || sub[0].depth != depth) {
         printf("%-28s n=%u: leaves hold %llu triangles, depth %u vs reported %u\n", name, n, (unsigned long long)leaf_tris, sub[0].depth, depth);
         return 1;
+    }
+    // --- the device's own validation, depth and compaction (steps 7 and 8), thread by thread, against finish ---------
+    {
+        std::vector<uint32_t> seen(n, 0), covered(n, 0), parent(n, 0xFFFFFFFFu), emitted(n, 0), new_index(n, 0);
+        uint32_t err = 0, dmax = 0;
+        for (uint32_t i = 0; i < n; i++) lbvh::check_order(order.data(), n, i, seen.data(), &err);
+        for (uint32_t i = 0; i + 1 < n; i++) emitted[i] = lbvh::check_node(ranges.data(), n, i, covered.data(), parent.data(), &err) ? 1u : 0u;
+        for (uint32_t i = 0; i < n; i++) lbvh::check_slot(covered.data(), i, &err);
+        if (err) { printf("%-28s n=%u: device validation refused a tree finish accepted (bits 0x%x)\n", name, n, err); return 1; }
+        for (uint32_t i = 0; i + 1 < n; i++)
+            if (emitted[i]) dmax = std::max(dmax, lbvh::node_depth(parent.data(), n, i, &err) + 1u);
+        uint32_t total = 0;
+        for (uint32_t i = 0; i < n; i++) { new_index[i] = total; total += emitted[i]; }
+        if (err || dmax != depth || total != nodes.size()) {
+            printf("%-28s n=%u: device finish disagrees: err 0x%x depth %u vs %u, %u vs %zu nodes\n", name, n, err, dmax, depth, total, nodes.size());
+            return 1;
+        }
+        std::vector<BvhNode> packed(total);
+        for (uint32_t i = 0; i + 1 < n; i++)
+            if (emitted[i]) packed[new_index[i]] = lbvh::compact_node(raw.data(), new_index.data(), i);
+        // same tree as finish's DFS-ordered one: walk both in lockstep
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 0u}};
+        size_t visited = 0;
+        while (!stack.empty()) {
+            auto [a, b] = stack.back();
+            stack.pop_back();
+            visited++;
+            const BvhNode &x = nodes[a], &y = packed[b];
+            if (memcmp(&x.lo_x_hi_x, &y.lo_x_hi_x, 3 * sizeof(float4)) != 0 || x.cnt[0] != y.cnt[0] || x.cnt[1] != y.cnt[1]) { printf("%s: compacted node differs\n", name); return 1; }
+            for (int c = 0; c < 2; c++) {
+                if ((x.child[c] >= 0) != (y.child[c] >= 0)) { printf("%s: compacted child kind differs\n", name); return 1; }
+                if (x.child[c] >= 0) stack.push_back({(uint32_t)x.child[c], (uint32_t)y.child[c]});
+                else if (x.child[c] != y.child[c]) { printf("%s: compacted leaf differs\n", name); return 1; }
+            }
+        }
+        if (visited != nodes.size()) { printf("%s: compacted tree has another size\n", name); return 1; }
+        // negative controls: one damaged range / order entry must be refused
+        if (n > 64) {
+            auto refused = [&](std::vector<Range> rg, std::vector<uint32_t> ord) {
+                std::vector<uint32_t> sn(n, 0), cv(n, 0), pr(n, 0xFFFFFFFFu);
+                uint32_t e = 0;
+                for (uint32_t i = 0; i < n; i++) lbvh::check_order(ord.data(), n, i, sn.data(), &e);
+                for (uint32_t i = 0; i + 1 < n; i++) lbvh::check_node(rg.data(), n, i, cv.data(), pr.data(), &e);
+                for (uint32_t i = 0; i < n; i++) lbvh::check_slot(cv.data(), i, &e);
+                return e != 0;
+            };
+            std::vector<Range> r1 = ranges, r2 = ranges, r3 = ranges;
+            std::vector<uint32_t> o1 = order;
+            uint32_t big = 0;  // some emitted inner node other than the root
+            for (uint32_t i = 1; i + 1 < n; i++)
+                if (lbvh::is_emitted(ranges[i], i) && ranges[i].last - ranges[i].first > 12) { big = i; break; }
+            r1[0].last = n - 2;
+            r2[big].split = r2[big].last;
+            r3[big].first += 1;
+            o1[3] = o1[4];
+            if (!refused(r1, order) || !refused(r2, order) || !refused(r3, order) || !refused(ranges, o1) || refused(ranges, order)) {
+                printf("%-28s n=%u: device validation let a damaged tree through\n", name, n);
+                return 1;
+            }
+        }
     }
     printf("%-28s n=%7u: ok, %zu nodes, depth %u\n", name, n, nodes.size(), depth);
     return 0;
