@@ -794,7 +794,7 @@ struct Env {
             for (int i = 0; i < hits.len; i++) {
                 const Hit &h = hits.hits[i];
                 if (!h.entering || h.distance < 0.0f) continue;
-                if (sub >= 64) throw std::runtime_error("more than 63 shadow photons behind one landing");
+                if (sub >= 1024) throw std::runtime_error("more than 1023 shadow photons behind one landing");
                 out.push_back(Photon{h.position, ray.direction, black(), PT_SHADOW, key_base + sub});
                 sub++;
             }
@@ -816,7 +816,7 @@ struct Env {
             float x = rng.u01() * total;
             int choice = x < c1 ? 0 : x < c2 ? 1 : x < c3 ? 2 : 3;
             // absorb_photon, photon_scene.rs:188-200
-            uint64_t key_base = index * 4096 + (uint64_t)bounce * 64;
+            uint64_t key_base = index * 65536 + (uint64_t)bounce * 1024;  // index | landing | sub-index, as the product keys its records
             Photon absorbed{hit.position, direction, intensity, PT_COLOUR, key_base};
             size_t slot = out.size();
             out.push_back(absorbed);

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
             float x = rng_u01(rng) * total;
             choice = x < c1 ? 0 : (x < c2 ? 1 : (x < c3 ? 2 : 3));
         }
-        uint64_t key_base = tag | (index * 4096ull + (uint64_t)bounce * 64ull);
+        // 56 bits: index (< 2^40) | landing (< 64) | sub-index (0 = the absorbed photon, 1..1023 = the shadow photons behind it)
+        uint64_t key_base = tag | (index * 65536ull + (uint64_t)bounce * 1024ull);
         // absorb_photon (photon_scene.rs:188-200); retagged Caustic on ReflectOrRefract (:176)
         bool caustic = choice == 3;
         store_photon(A.out[0], alive && !(caustic || dest_absorb_default), h.position, dir, intensity, RRT_PHOTON_COLOUR, key_base, err);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
                     float t = 0.0f;
                     uint32_t sb;
                     bool have = alive && single_entering_hit(S, rec, so, sd, RRT_INF, lds, cnt, t, sb);
-                    if (have && sub >= 64) {
+                    if (have && sub >= 1024) {
                         err |= RRT_ERR_BIT_SHADOW_CAP;
                         have = false;
                     }
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
                             have = (m & META_ENTER) && !(t < 0.0f);
                         }
                         if (!__any(have)) continue;
-                        if (have && sub >= 64) {
+                        if (have && sub >= 1024) {
                             err |= RRT_ERR_BIT_SHADOW_CAP;
                             have = false;
                         }
@@ -756,7 +757,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         if (err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");
         if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
         if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
-        if (err & 4u) return fail(RRT_ERR_LIMIT, "more than 63 shadow photons behind one landing");
+        if (err & 4u) return fail(RRT_ERR_LIMIT, "more than 1023 shadow photons behind one landing");
         SegmentPrefix P[2];
         bool overflow = (err & PH_ERR_CAPACITY) != 0;
         for (int w = 0; w < 2; w++) {

@@ -378,3 +378,28 @@ def test_exchange_buffers_are_exactly_as_large_as_the_header_says(repo):
         pa, pb = a.photon_read(which), b.photon_read(which)
         for k in pa:
             assert np.array_equal(pa[k].view(np.uint8), pb[k].view(np.uint8)), (which, k)
+
+
+def test_more_than_63_shadow_photons_behind_one_landing(repo):
+    """shadowphotontrace (photon_scene.rs:202-228) stores one shadow photon per entering surface behind a landing and has
+    no limit; record keys give the sub-index 10 bits (round 1: 6, and a row of 70 spheres could not be photon-mapped).
+    A photon that lands on the outermost of 90 concentric spheres, heading for the centre, leaves 89 shadow photons behind it."""
+    import scene_kit as kit
+
+    params = rrt.default_params(photons_per_light=3000, caustic_photons_per_light=100)
+    scenes = []
+    for cls in (ob.OracleScene, rrt.Scene):
+        s = cls(abi.MODE_PHOTON, params)
+        m = kit.monochrome(s, (0.8, 0.3, 0.2))
+        for k in range(90):
+            s.add_object(kit.sphere(s, (0.0, 0.0, 10.0), 0.5 + 0.05 * k, m))
+        kit.light(s, abi.LIGHT_POINT, position=(0.0, 0.0, 0.0), colour=(1, 1, 1))
+        s.pre_render(4)
+        scenes.append(s)
+    cpu, gpu = scenes
+    pc, pg = cpu.photon_read(0), gpu.photon_read(0)
+    assert np.array_equal(pc["key"], pg["key"]) and np.array_equal(pc["type"], pg["type"])
+    for k in ("position", "incident", "intensity"):
+        assert np.array_equal(bits(pc[k]), bits(pg[k])), k
+    sub = pg["key"] & np.uint64(1023)
+    assert sub.max() >= 80, sub.max()          # far more than the 63 the old layout could name
