@@ -17,13 +17,15 @@
 
 namespace rrt {
 
+#ifndef RRT_BLOCK
 #define RRT_BLOCK 256
+#endif
 
 extern __shared__ float4 g_smem[];
 
-__device__ __forceinline__ Lds make_lds(uint32_t lds_slots) {
+__device__ __forceinline__ Lds make_lds(uint32_t lds_slots, uint32_t nthreads = RRT_BLOCK) {
     Lds l;
-    l.nthreads = RRT_BLOCK;
+    l.nthreads = nthreads;
     l.tid = threadIdx.x;
     l.le = reinterpret_cast<float2 *>(g_smem);
     l.stack = reinterpret_cast<int *>(g_smem);
@@ -135,14 +137,17 @@ __device__ __forceinline__ f3 scene_node_total(f3 once, uint32_t flags, float wr
 #endif
 // MODE is a template parameter so that the raytracing-mode instance does not carry the registers of the photon
 // gather and vice versa (occupancy is VGPR-limited here).
-template <int MODE, int FEAT>
-__global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
+// BLOCK: threads per block.  256 where child rays are appended (one atomic per block on the queue counter); 64 for
+// single-level frames (A.fuse: nothing is appended), where a block's registers and LDS return to the pool as soon as its
+// one wave is done instead of waiting for the slowest of four (mesh frame: 1.35 -> 1.22 ms).
+template <int MODE, int FEAT, int BLOCK>
+__global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
     const DevScene &S = A.S;
-    Lds lds = make_lds(A.lds_slots);
-    uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
+    Lds lds = make_lds(A.lds_slots, BLOCK);
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t count = A.count_ptr ? min(*A.count_ptr, A.count) : A.count;
     bool active = i < count;
-    if (blockIdx.x * RRT_BLOCK >= count) return;  // launched for the predicted size of the level
+    if (blockIdx.x * BLOCK >= count) return;  // launched for the predicted size of the level
     Counters cnt = {0, 0, 0, 0};
     unsigned long long gathered = 0, queries = 0, candidates = 0;
     bool want_a = false, want_b = false;  // a: reflection child, b: refraction child
@@ -296,9 +301,9 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
     // Per wave a 64-bit ballot + lane-prefix popcount gives each lane its slot inside the wave's share; the four waves'
     // shares are laid end to end through LDS and thread 0 reserves the block's total with a single atomicAdd (one
     // atomic per wave on the one queue counter serialises in the L2: 32 k waves at 1080p).
-    __shared__ uint32_t s_wave_a[RRT_BLOCK / 64], s_wave_b[RRT_BLOCK / 64];
+    __shared__ uint32_t s_wave_a[BLOCK / 64], s_wave_b[BLOCK / 64];
     __shared__ uint32_t s_block_base;
-    __shared__ unsigned long long s_stat[RRT_BLOCK / 64][ST_COUNT];
+    __shared__ unsigned long long s_stat[BLOCK / 64][ST_COUNT];
     __shared__ uint32_t s_err;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
@@ -320,13 +325,13 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
     if (threadIdx.x < ST_COUNT) {  // thread k owns statistic k
         unsigned long long sum = 0;
 #pragma unroll
-        for (int w = 0; w < RRT_BLOCK / 64; w++) sum += s_stat[w][threadIdx.x];
+        for (int w = 0; w < BLOCK / 64; w++) sum += s_stat[w][threadIdx.x];
         if (sum) atomicAdd(&A.stats[(blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE + threadIdx.x], sum);
     }
     if (threadIdx.x == 0) {
         uint32_t block_total = 0;
 #pragma unroll
-        for (int w = 0; w < RRT_BLOCK / 64; w++) block_total += s_wave_a[w] + s_wave_b[w];
+        for (int w = 0; w < BLOCK / 64; w++) block_total += s_wave_a[w] + s_wave_b[w];
         s_block_base = block_total ? atomicAdd(A.next_count, block_total) : 0u;
     }
     __syncthreads();
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
         // the block's reflection rays first, then its refraction rays: a wave of the next level then holds one kind of
         // ray from one 8x8-tile neighbourhood, which keeps its rays together at the bound boxes
         uint32_t all_a = 0, base_a = s_block_base, base_b = s_block_base;
-        for (uint32_t w = 0; w < RRT_BLOCK / 64; w++) {
+        for (uint32_t w = 0; w < BLOCK / 64; w++) {
             all_a += s_wave_a[w];
             if (w < wave) {
                 base_a += s_wave_a[w];
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceA
         unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
         uint32_t off_a = base_a + __popcll(ma & below), off_b = base_b + __popcll(mb & below);
         uint32_t block_end = s_block_base;
-        for (uint32_t w = 0; w < RRT_BLOCK / 64; w++) block_end += s_wave_a[w] + s_wave_b[w];
+        for (uint32_t w = 0; w < BLOCK / 64; w++) block_end += s_wave_a[w] + s_wave_b[w];
         if (block_end > A.next_limit) {  // prediction too small: the host repeats the frame level by level
             if (lane == 0) atomicOr(A.err, RRT_ERR_BIT_QUEUE);
             want_a = want_b = false;
@@ -536,8 +541,15 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
     if (a.count == 0) return;
     // one instance per (mode, scene feature set): see SceneFeatures in dev_trace.h
     const int feat = (a.S.has_csg ? FEAT_CSG : 0) | (a.S.n_meshes ? FEAT_MESH : 0);
-    dim3 grid(blocks_for(a.count)), block(RRT_BLOCK);
-#define RRT_LAUNCH(M, F) hipLaunchKernelGGL((k_trace_shade<M, F>), grid, block, lds_bytes, stream, a)
+    // the hit lists / BVH stacks are laid out [element][thread]: the bytes scale with the block
+    const bool narrow = a.mode == RRT_MODE_SCENE && a.fuse;
+#define RRT_LAUNCH(M, F)                                                                                                                \
+    do {                                                                                                                                \
+        if (narrow)                                                                                                                     \
+            hipLaunchKernelGGL((k_trace_shade<M, F, 64>), dim3((a.count + 63u) / 64u), dim3(64), lds_bytes / 256 * 64, stream, a);      \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((k_trace_shade<M, F, RRT_BLOCK>), dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes / 256 * RRT_BLOCK, stream, a); \
+    } while (0)
     if (a.mode == RRT_MODE_SCENE) {
         switch (feat) {
             case 0: RRT_LAUNCH(RRT_MODE_SCENE, 0); break;
@@ -566,11 +578,11 @@ void launch_combine(const TraceArgs &a, hipStream_t stream) {
 }
 void launch_batch_trace(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream) {
     if (a.n == 0) return;
-    hipLaunchKernelGGL(k_batch_trace, dim3(blocks_for(a.n)), dim3(RRT_BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL(k_batch_trace, dim3(blocks_for(a.n)), dim3(RRT_BLOCK), lds_bytes / 256 * RRT_BLOCK, stream, a);
 }
 void launch_batch_shadow(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream) {
     if (a.n == 0) return;
-    hipLaunchKernelGGL(k_batch_shadow, dim3(blocks_for(a.n)), dim3(RRT_BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL(k_batch_shadow, dim3(blocks_for(a.n)), dim3(RRT_BLOCK), lds_bytes / 256 * RRT_BLOCK, stream, a);
 }
 void launch_load_rays(const float *origins, const float *directions, uint32_t n, LevelBuffers lv, hipStream_t stream) {
     if (n == 0) return;
