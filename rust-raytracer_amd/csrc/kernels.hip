@@ -137,9 +137,7 @@ __device__ __forceinline__ f3 scene_node_total(f3 once, uint32_t flags, float wr
 #endif
 // MODE is a template parameter so that the raytracing-mode instance does not carry the registers of the photon
 // gather and vice versa (occupancy is VGPR-limited here).
-// BLOCK: threads per block.  256 where child rays are appended (one atomic per block on the queue counter); 64 for
-// single-level frames (A.fuse: nothing is appended), where a block's registers and LDS return to the pool as soon as its
-// one wave is done instead of waiting for the slowest of four (mesh frame: 1.35 -> 1.22 ms).
+// BLOCK: threads per block, 64 or 256 (launch_trace_shade says which and why).
 template <int MODE, int FEAT, int BLOCK>
 __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
     const DevScene &S = A.S;
@@ -541,31 +539,33 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
     if (a.count == 0) return;
     // one instance per (mode, scene feature set): see SceneFeatures in dev_trace.h
     const int feat = (a.S.has_csg ? FEAT_CSG : 0) | (a.S.n_meshes ? FEAT_MESH : 0);
-    // the hit lists / BVH stacks are laid out [element][thread]: the bytes scale with the block
-    const bool narrow = a.mode == RRT_MODE_SCENE && a.fuse;
-#define RRT_LAUNCH(M, F)                                                                                                                \
-    do {                                                                                                                                \
-        if (narrow)                                                                                                                     \
-            hipLaunchKernelGGL((k_trace_shade<M, F, 64>), dim3((a.count + 63u) / 64u), dim3(64), lds_bytes / 256 * 64, stream, a);      \
-        else                                                                                                                            \
-            hipLaunchKernelGGL((k_trace_shade<M, F, RRT_BLOCK>), dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes / 256 * RRT_BLOCK, stream, a); \
-    } while (0)
+    // The hit lists / BVH stacks are laid out [element][thread]: the bytes scale with the block.
+    // Block size: 64 threads, except raytracing mode on scenes with CSG objects.  A block's registers and LDS return to the
+    // pool when its LAST wave is done, and rays differ widely in cost (BVH depth, photon gathers), so one-wave blocks keep
+    // the SIMDs fuller: 4K mesh frame 1.35 -> 1.21 ms, with mirror / glass teapots +4 / +9 %, photon-mapped scene2 +2 %
+    // (+10 % with three frames in flight), although every wave then pays its own atomic on the queue counter.  The
+    // raytraced CSG scene is the exception (9.6 -> 7.6 Grays/s with one-wave blocks: most of its pixels append two
+    // children), it keeps 256.
+#define RRT_NARROW(M, F) hipLaunchKernelGGL((k_trace_shade<M, F, 64>), dim3((a.count + 63u) / 64u), dim3(64), lds_bytes / 256 * 64, stream, a)
+#define RRT_WIDE(M, F) \
+    hipLaunchKernelGGL((k_trace_shade<M, F, RRT_BLOCK>), dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes / 256 * RRT_BLOCK, stream, a)
     if (a.mode == RRT_MODE_SCENE) {
         switch (feat) {
-            case 0: RRT_LAUNCH(RRT_MODE_SCENE, 0); break;
-            case FEAT_CSG: RRT_LAUNCH(RRT_MODE_SCENE, FEAT_CSG); break;
-            case FEAT_MESH: RRT_LAUNCH(RRT_MODE_SCENE, FEAT_MESH); break;
-            default: RRT_LAUNCH(RRT_MODE_SCENE, FEAT_ALL); break;
+            case 0: RRT_NARROW(RRT_MODE_SCENE, 0); break;
+            case FEAT_CSG: RRT_WIDE(RRT_MODE_SCENE, FEAT_CSG); break;
+            case FEAT_MESH: RRT_NARROW(RRT_MODE_SCENE, FEAT_MESH); break;
+            default: RRT_WIDE(RRT_MODE_SCENE, FEAT_ALL); break;
         }
     } else {
         switch (feat) {
-            case 0: RRT_LAUNCH(RRT_MODE_PHOTON, 0); break;
-            case FEAT_CSG: RRT_LAUNCH(RRT_MODE_PHOTON, FEAT_CSG); break;
-            case FEAT_MESH: RRT_LAUNCH(RRT_MODE_PHOTON, FEAT_MESH); break;
-            default: RRT_LAUNCH(RRT_MODE_PHOTON, FEAT_ALL); break;
+            case 0: RRT_NARROW(RRT_MODE_PHOTON, 0); break;
+            case FEAT_CSG: RRT_NARROW(RRT_MODE_PHOTON, FEAT_CSG); break;
+            case FEAT_MESH: RRT_NARROW(RRT_MODE_PHOTON, FEAT_MESH); break;
+            default: RRT_NARROW(RRT_MODE_PHOTON, FEAT_ALL); break;
         }
     }
-#undef RRT_LAUNCH
+#undef RRT_NARROW
+#undef RRT_WIDE
 }
 void launch_gather_heavy(const TraceArgs &a, hipStream_t stream) {
     if (!a.heavy || a.mode != RRT_MODE_PHOTON) return;
