@@ -138,7 +138,9 @@ __device__ __forceinline__ f3 scene_node_total(f3 once, uint32_t flags, float wr
 // MODE is a template parameter so that the raytracing-mode instance does not carry the registers of the photon
 // gather and vice versa (occupancy is VGPR-limited here).
 // BLOCK: threads per block, 64 or 256 (launch_trace_shade says which and why).
-template <int MODE, int FEAT, int BLOCK>
+// FUSE: single-level frames (TraceArgs.fuse; raytracing mode only): a compile-time constant so that this instance carries
+// neither the child-ray state nor the node arrays' addresses across the shadow traversal.
+template <int MODE, int FEAT, int BLOCK, bool FUSE>
 __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
     const DevScene &S = A.S;
     Lds lds = make_lds(A.lds_slots, BLOCK);
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
         }
         // Fused single-level frames (A.fuse: raytracing mode, no material spawns rays, so level 0 is the whole
         // recursion): the pixel is finished here with k_combine's arithmetic and nothing goes through the node arrays.
-        const bool fuse = MODE == RRT_MODE_SCENE && A.fuse;
+        constexpr bool fuse = MODE == RRT_MODE_SCENE && FUSE;
         const uint32_t out_pixel = fuse ? (A.cam.width ? node_pixel(A.pixel_base + i, A.cam.width, A.band_rows) : A.pixel_base + i) : 0u;
         if (tr.object == 0xFFFFFFFFu) {  // scene.rs:85-90 / photon_scene.rs:311-313
             if (fuse) {
@@ -188,30 +190,10 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
             }
             if (MODE == RRT_MODE_SCENE) {
                 f3 once = material_once_pre(S, M, h, cnt);
-                float wr = 0.0f, wt = 0.0f;
-                if (M.global_part >= 0) {  // GlobalMaterial::compute_once, global_material.rs:71-98
-                    const MatPart &G = M.parts[M.global_part];
-                    flags |= NF_HAS_GLOBAL;
-                    wr = G.wr;
-                    wt = G.wt;
-                    if (A.level < A.max_depth) {
-                        flags |= NF_GLOBAL_ACTIVE;
-                        if (wr > 0.0f) {
-                            ad = norm3(reflect3(h.normal, d));
-                            ao = h.position + ad * 0.0001f;
-                            want_a = true;
-                        }
-                        if (wt > 0.0f) want_b = global_refraction(G, h, true, d, bo, bd, kr);
-                    }
-                }
                 const float div = M.is_compound ? (float)M.n_parts : 0.0f;
                 f3 colour = mk3(0.0f, 0.0f, 0.0f);
-                if (fuse) {
-                    colour = scene_node_total(once, flags, wr, wt, div, kr, false, colour, false, colour);
-                } else {
-                    A.cur.once[i] = make_float4(once.x, once.y, once.z, kr);
-                    A.cur.glob[i] = make_float4(wr, wt, div, __uint_as_float(flags));
-                }
+                // (a fused frame has no material with a Global part: that is what makes it single-level)
+                if (fuse) colour = scene_node_total(once, flags, 0.0f, 0.0f, div, kr, false, colour, false, colour);
                 // scene.rs:96-122
                 for (uint32_t l = 0; l < S.n_lights; l++) {
                     const DevLight L = S.lights[l];
@@ -232,7 +214,29 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
                         A.cur.lights[(size_t)l * A.cur.capacity + i] = make_float4(term.x, term.y, term.z, lit ? 1.0f : 0.0f);
                     }
                 }
-                if (fuse) write_pixel(A, out_pixel, colour, tr.t, tr.object);
+                if (fuse) {
+                    write_pixel(A, out_pixel, colour, tr.t, tr.object);
+                } else {
+                    // the child rays come after the light loop: nothing of them is live across the shadow traversals
+                    float wr = 0.0f, wt = 0.0f;
+                    if (M.global_part >= 0) {  // GlobalMaterial::compute_once, global_material.rs:71-98
+                        const MatPart &G = M.parts[M.global_part];
+                        flags |= NF_HAS_GLOBAL;
+                        wr = G.wr;
+                        wt = G.wt;
+                        if (A.level < A.max_depth) {
+                            flags |= NF_GLOBAL_ACTIVE;
+                            if (wr > 0.0f) {
+                                ad = norm3(reflect3(h.normal, d));
+                                ao = h.position + ad * 0.0001f;
+                                want_a = true;
+                            }
+                            if (wt > 0.0f) want_b = global_refraction(G, h, true, d, bo, bd, kr);
+                        }
+                    }
+                    A.cur.once[i] = make_float4(once.x, once.y, once.z, kr);
+                    A.cur.glob[i] = make_float4(wr, wt, div, __uint_as_float(flags));
+                }
             } else {  // PhotonScene::vueontrace, photon_scene.rs:309-361
                 float sw = M.surface_weight, rw = M.w[3];
                 f3 surface = mk3(0.0f, 0.0f, 0.0f);
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
             A.next.ray_d[off_b] = make_float4(bd.x, bd.y, bd.z, __uint_as_float(1u));
         }
     }
-    if (active && !(MODE == RRT_MODE_SCENE && A.fuse)) A.cur.child[i] = child;
+    if (active && !(MODE == RRT_MODE_SCENE && FUSE)) A.cur.child[i] = child;
 }
 
 // Photon mode: the radiance estimates the trace kernel filed (HeavyRec), one query per wave.  Grid-stride over the
@@ -546,24 +550,32 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
     // (+10 % with three frames in flight), although every wave then pays its own atomic on the queue counter.  The
     // raytraced CSG scene is the exception (9.6 -> 7.6 Grays/s with one-wave blocks: most of its pixels append two
     // children), it keeps 256.
-#define RRT_NARROW(M, F) hipLaunchKernelGGL((k_trace_shade<M, F, 64>), dim3((a.count + 63u) / 64u), dim3(64), lds_bytes / 256 * 64, stream, a)
-#define RRT_WIDE(M, F) \
-    hipLaunchKernelGGL((k_trace_shade<M, F, RRT_BLOCK>), dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes / 256 * RRT_BLOCK, stream, a)
+#define RRT_NARROW(M, F, U) hipLaunchKernelGGL((k_trace_shade<M, F, 64, U>), dim3((a.count + 63u) / 64u), dim3(64), lds_bytes / 256 * 64, stream, a)
+#define RRT_WIDE(M, F, U) \
+    hipLaunchKernelGGL((k_trace_shade<M, F, RRT_BLOCK, U>), dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes / 256 * RRT_BLOCK, stream, a)
+#define RRT_EITHER(WHICH, M, F)    \
+    do {                           \
+        if (a.fuse)                \
+            WHICH(M, F, true);     \
+        else                       \
+            WHICH(M, F, false);    \
+    } while (0)
     if (a.mode == RRT_MODE_SCENE) {
         switch (feat) {
-            case 0: RRT_NARROW(RRT_MODE_SCENE, 0); break;
-            case FEAT_CSG: RRT_WIDE(RRT_MODE_SCENE, FEAT_CSG); break;
-            case FEAT_MESH: RRT_NARROW(RRT_MODE_SCENE, FEAT_MESH); break;
-            default: RRT_WIDE(RRT_MODE_SCENE, FEAT_ALL); break;
+            case 0: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, 0); break;
+            case FEAT_CSG: RRT_EITHER(RRT_WIDE, RRT_MODE_SCENE, FEAT_CSG); break;
+            case FEAT_MESH: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, FEAT_MESH); break;
+            default: RRT_EITHER(RRT_WIDE, RRT_MODE_SCENE, FEAT_ALL); break;
         }
     } else {
         switch (feat) {
-            case 0: RRT_NARROW(RRT_MODE_PHOTON, 0); break;
-            case FEAT_CSG: RRT_NARROW(RRT_MODE_PHOTON, FEAT_CSG); break;
-            case FEAT_MESH: RRT_NARROW(RRT_MODE_PHOTON, FEAT_MESH); break;
-            default: RRT_NARROW(RRT_MODE_PHOTON, FEAT_ALL); break;
+            case 0: RRT_NARROW(RRT_MODE_PHOTON, 0, false); break;
+            case FEAT_CSG: RRT_NARROW(RRT_MODE_PHOTON, FEAT_CSG, false); break;
+            case FEAT_MESH: RRT_NARROW(RRT_MODE_PHOTON, FEAT_MESH, false); break;
+            default: RRT_NARROW(RRT_MODE_PHOTON, FEAT_ALL, false); break;
         }
     }
+#undef RRT_EITHER
 #undef RRT_NARROW
 #undef RRT_WIDE
 }
