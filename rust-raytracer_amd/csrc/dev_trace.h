@@ -199,45 +199,55 @@ __device__ __forceinline__ bool tri_test(const TriHot &T, f3 o, f3 d, float &t, 
 //    against origin + e, upper faces against origin - e.  That covers the rounding of o + d*t in the reference's hit
 //    point and of the slab distances here, each of which is ONE fma on the quantised coordinate:
 //        t = q * (qscale / d) + (qbase - (o +- e)) / d
+//    (which of a pair of faces the ray meets first follows from the sign of 1/d alone: make_slabs)
 //  * the far end of the [near, far] interval is widened by a relative 2^-18 (1/d is a 1-ulp reciprocal).
 // Reciprocals are clamped to +-2^60 and rays or meshes with coordinates beyond 2^60 (or not finite) skip the pruning
 // altogether (every node is visited), so no inf - inf can turn a slab distance into a NaN that min/max would drop on the
 // wrong side.  None of this arithmetic is part of the parity contract (it only prunes): it may fuse and approximate.
 struct RaySlabs {
-    f3 a, blo, bhi;
+    f3 a, bn, bf;             // per axis: slope, offset of the face the ray meets first, offset of the one it leaves through
+    uint32_t sx, sy, sz;      // per axis: 0, or 16 when the ray runs towards smaller coordinates (it then enters through the upper face)
 };
 __device__ __forceinline__ RaySlabs make_slabs(const MeshInfo &M, f3 o, f3 d) {
     const float lim = 1152921504606846976.0f;  // 2^60
     const float omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
     RaySlabs r;
+    r.sx = r.sy = r.sz = 0u;
     if (M.wild || !(omax < lim)) {  // no pruning: every slab distance is 0, every box "hit"
-        r.a = r.blo = r.bhi = mk3(0.0f, 0.0f, 0.0f);
+        r.a = r.bn = r.bf = mk3(0.0f, 0.0f, 0.0f);
         return r;
     }
     f3 inv = mk3(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -lim, lim), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -lim, lim),
                  __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -lim, lim));
     const float e = (omax + M.qmag) * 9.5367431640625e-7f;  // 2^-20
     r.a = mk3(M.qscale[0] * inv.x, M.qscale[1] * inv.y, M.qscale[2] * inv.z);
-    r.blo = mk3((M.qbase[0] - (o.x + e)) * inv.x, (M.qbase[1] - (o.y + e)) * inv.y, (M.qbase[2] - (o.z + e)) * inv.z);
-    r.bhi = mk3((M.qbase[0] - (o.x - e)) * inv.x, (M.qbase[1] - (o.y - e)) * inv.y, (M.qbase[2] - (o.z - e)) * inv.z);
+    const f3 blo = mk3((M.qbase[0] - (o.x + e)) * inv.x, (M.qbase[1] - (o.y + e)) * inv.y, (M.qbase[2] - (o.z + e)) * inv.z);
+    const f3 bhi = mk3((M.qbase[0] - (o.x - e)) * inv.x, (M.qbase[1] - (o.y - e)) * inv.y, (M.qbase[2] - (o.z - e)) * inv.z);
+    // With a positive reciprocal the lower face (grid word's low half, offset blo) has the smaller slab distance, with a
+    // negative one the upper face (high half, bhi): q_lo <= q_hi, blo <= bhi resp. >=, and an fma is monotone.  Which is
+    // which is settled here once per ray instead of by a min and a max per face pair and node.
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    r.sx = nx ? 16u : 0u, r.sy = ny ? 16u : 0u, r.sz = nz ? 16u : 0u;
+    r.bn = mk3(nx ? bhi.x : blo.x, ny ? bhi.y : blo.y, nz ? bhi.z : blo.z);
+    r.bf = mk3(nx ? blo.x : bhi.x, ny ? blo.y : bhi.y, nz ? blo.z : bhi.z);
     return r;
 }
 __device__ __forceinline__ void box2_test(const BvhNodeQ &N, const RaySlabs &R, float tmax, bool &hit_l, bool &hit_r, float &near_l,
                                           float &near_r) {
-#define RRT_QLO(w) ((float)((w) & 0xFFFFu))
-#define RRT_QHI(w) ((float)((w) >> 16))
-    float lx0 = __builtin_fmaf(RRT_QLO(N.q[0]), R.a.x, R.blo.x), lx1 = __builtin_fmaf(RRT_QHI(N.q[0]), R.a.x, R.bhi.x);
-    float rx0 = __builtin_fmaf(RRT_QLO(N.q[1]), R.a.x, R.blo.x), rx1 = __builtin_fmaf(RRT_QHI(N.q[1]), R.a.x, R.bhi.x);
-    float ly0 = __builtin_fmaf(RRT_QLO(N.q[2]), R.a.y, R.blo.y), ly1 = __builtin_fmaf(RRT_QHI(N.q[2]), R.a.y, R.bhi.y);
-    float ry0 = __builtin_fmaf(RRT_QLO(N.q[3]), R.a.y, R.blo.y), ry1 = __builtin_fmaf(RRT_QHI(N.q[3]), R.a.y, R.bhi.y);
-    float lz0 = __builtin_fmaf(RRT_QLO(N.q[4]), R.a.z, R.blo.z), lz1 = __builtin_fmaf(RRT_QHI(N.q[4]), R.a.z, R.bhi.z);
-    float rz0 = __builtin_fmaf(RRT_QLO(N.q[5]), R.a.z, R.blo.z), rz1 = __builtin_fmaf(RRT_QHI(N.q[5]), R.a.z, R.bhi.z);
-#undef RRT_QLO
-#undef RRT_QHI
-    float ln = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fminf(lz0, lz1));
-    float lf = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fmaxf(lz0, lz1));
-    float rn = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fminf(rz0, rz1));
-    float rf = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fmaxf(rz0, rz1));
+    // grid word = lo | hi << 16; rotated by the ray's shift its LOW half is the face the ray meets first
+#define RRT_ROT(w, s) __builtin_amdgcn_alignbit((w), (w), (s))
+#define RRT_QN(w) ((float)((w) & 0xFFFFu))
+#define RRT_QF(w) ((float)((w) >> 16))
+    const uint32_t lx = RRT_ROT(N.q[0], R.sx), rx = RRT_ROT(N.q[1], R.sx);
+    const uint32_t ly = RRT_ROT(N.q[2], R.sy), ry = RRT_ROT(N.q[3], R.sy);
+    const uint32_t lz = RRT_ROT(N.q[4], R.sz), rz = RRT_ROT(N.q[5], R.sz);
+    const float ln = fmaxf(fmaxf(__builtin_fmaf(RRT_QN(lx), R.a.x, R.bn.x), __builtin_fmaf(RRT_QN(ly), R.a.y, R.bn.y)), __builtin_fmaf(RRT_QN(lz), R.a.z, R.bn.z));
+    const float lf = fminf(fminf(__builtin_fmaf(RRT_QF(lx), R.a.x, R.bf.x), __builtin_fmaf(RRT_QF(ly), R.a.y, R.bf.y)), __builtin_fmaf(RRT_QF(lz), R.a.z, R.bf.z));
+    const float rn = fmaxf(fmaxf(__builtin_fmaf(RRT_QN(rx), R.a.x, R.bn.x), __builtin_fmaf(RRT_QN(ry), R.a.y, R.bn.y)), __builtin_fmaf(RRT_QN(rz), R.a.z, R.bn.z));
+    const float rf = fminf(fminf(__builtin_fmaf(RRT_QF(rx), R.a.x, R.bf.x), __builtin_fmaf(RRT_QF(ry), R.a.y, R.bf.y)), __builtin_fmaf(RRT_QF(rz), R.a.z, R.bf.z));
+#undef RRT_ROT
+#undef RRT_QN
+#undef RRT_QF
     const float K = 1.000003814697265625f;  // 1 + 2^-18
     // hit: the interval [max(near, 0), min(far, tmax)] is not empty once its far end is widened
     hit_l = lf >= 0.0f && ln <= fminf(lf, tmax) * K;
