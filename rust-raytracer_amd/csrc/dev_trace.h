@@ -280,7 +280,9 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
                 cnt.overflow |= 16u;              // RRT_ERR_BIT_INTERNAL
                 break;
             }
-            const BvhNodeQ N = nodes[cur];
+            // 32 bytes per node and fewer than 2^27 nodes per mesh: the byte offset fits 32 bits, so the load can take the
+            // mesh's base from SGPRs and ONE vector register of offset (no 64-bit address arithmetic per visit)
+            const BvhNodeQ N = *reinterpret_cast<const BvhNodeQ *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)cur << 5));
             bool hl, hr;
             float nl, nr;
             box2_test(N, slabs, best, hl, hr, nl, nr);
