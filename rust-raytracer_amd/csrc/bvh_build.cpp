@@ -232,7 +232,7 @@ void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order,
 // Containment is checked in exact arithmetic: qbase + q * qscale is exact in double (24-bit x 16-bit product, 24-bit
 // addend), so "decoded lower face <= box lower face" holds for the real numbers the device's fma approximates; the
 // device's own rounding is covered by its pad (dev_trace.h, make_slabs).
-void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<BvhNodeQ> &out) {
+void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<BvhNodeQ> &out, uint32_t &stack_need) {
     const float lim = 1152921504606846976.0f;  // 2^60
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool wild = nodes.empty();
@@ -278,23 +278,97 @@ void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<B
         while (q < 65535.0 && base + q * sc < (double)v) q += 1.0;
         return (uint32_t)q;
     };
-    out.resize(nodes.size());
-    for (size_t k = 0; k < nodes.size(); k++) {
-        const BvhNode &n = nodes[k];
-        BvhNodeQ &o = out[k];
+
+    // ---- collapse to four children per node ------------------------------------------------------------------------
+    // A node starts with the two children of its BVH2 node; as long as it has room, the inner child with the largest
+    // surface takes its own two children's place (the box it would have been tested with is then never tested: the
+    // grandchildren's boxes lie inside it).  The tree keeps exactly the BVH2's leaves and their boxes, so it prunes
+    // nothing the BVH2 would not prune.
+    struct Slot {
+        float lo[3], hi[3];
+        int32_t ref;   // >= 0: BVH2 node index; < 0: leaf, ~ref = first slot
+        uint32_t cnt;  // leaf: triangles
+    };
+    auto slot_of = [&](const BvhNode &n, int c, Slot &s) -> bool {
         for (int a = 0; a < 3; a++) {
             const float4 &b = box_axis(n, a);
             const float v[4] = {b.x, b.y, b.z, b.w};
-            for (int c = 0; c < 2; c++) {
-                const float l = v[c], h = v[2 + c];
-                // an empty child stays empty (lower face above upper face) unless the mesh is wild
-                const uint32_t ql = (l > h && !wild) ? 65535u : q_down(l, a), qh = (l > h && !wild) ? 0u : q_up(h, a);
-                o.q[2 * a + c] = ql | (qh << 16);
+            s.lo[a] = v[c];
+            s.hi[a] = v[2 + c];
+        }
+        s.ref = n.child[c];
+        s.cnt = n.cnt[c];
+        // an empty child (lower face above upper face on some axis; bvh_build.cpp writes them for meshes of <= 4 triangles)
+        // takes no slot, unless the mesh is wild and boxes mean nothing
+        if (!wild && (s.lo[0] > s.hi[0] || s.lo[1] > s.hi[1] || s.lo[2] > s.hi[2])) return false;
+        return true;
+    };
+    auto area = [](const Slot &s) -> double {
+        const double x = (double)s.hi[0] - s.lo[0], y = (double)s.hi[1] - s.lo[1], z = (double)s.hi[2] - s.lo[2];
+        const double A = x * y + y * z + z * x;
+        return A == A ? A : INFINITY;  // NaN boxes first: whatever is below them gets its own test
+    };
+    out.clear();
+    stack_need = 0;
+    if (nodes.empty()) return;
+    struct Work {
+        uint32_t src, dst;
+    };
+    std::vector<Work> work;
+    std::vector<uint32_t> parent_need;  // per output node: stack entries in use when the traversal arrives at it, at most
+    out.emplace_back();
+    parent_need.push_back(0);
+    work.push_back({0u, 0u});
+    while (!work.empty()) {
+        const Work w = work.back();
+        work.pop_back();
+        Slot sl[4];
+        int m = 0;
+        for (int c = 0; c < 2; c++)
+            if (slot_of(nodes[w.src], c, sl[m])) m++;
+        for (;;) {
+            if (m >= 4) break;
+            int pick = -1;
+            double best = -1.0;
+            for (int k = 0; k < m; k++)
+                if (sl[k].ref >= 0 && area(sl[k]) > best) best = area(sl[k]), pick = k;
+            if (pick < 0) break;
+            const BvhNode &n = nodes[sl[pick].ref];
+            Slot a, b;
+            const bool ha = slot_of(n, 0, a), hb = slot_of(n, 1, b);
+            // the picked slot is replaced in place by the first grandchild, the second goes to the end
+            if (ha && hb) {
+                sl[pick] = a;
+                sl[m++] = b;
+            } else if (ha || hb) {
+                sl[pick] = ha ? a : b;
+            } else {  // both empty: the slot disappears
+                sl[pick] = sl[--m];
             }
         }
-        for (int c = 0; c < 2; c++)
-            o.child[c] = n.child[c] >= 0 ? n.child[c] : -(int32_t)((((uint32_t)(~n.child[c])) << 4) | (n.cnt[c] & 15u)) - 1;
+        BvhNodeQ o;
+        for (int k = 0; k < 4; k++) {
+            for (int a = 0; a < 3; a++) o.q[4 * a + k] = 65535u | (0u << 16);  // empty: lower face above upper face
+            o.child[k] = RRT_BVH_EMPTY;
+        }
+        // stack entries while below this node: what was there on arrival + its other children
+        const uint32_t below = parent_need[w.dst] + (m > 0 ? (uint32_t)m - 1u : 0u);
+        stack_need = std::max(stack_need, below);
+        for (int k = 0; k < m; k++) {
+            for (int a = 0; a < 3; a++) o.q[4 * a + k] = q_down(sl[k].lo[a], a) | (q_up(sl[k].hi[a], a) << 16);
+            if (sl[k].ref >= 0) {
+                const uint32_t dst = (uint32_t)out.size();
+                out.emplace_back();
+                parent_need.push_back(below);
+                work.push_back({(uint32_t)sl[k].ref, dst});
+                o.child[k] = (int32_t)dst;
+            } else {
+                o.child[k] = -(int32_t)((((uint32_t)(~sl[k].ref)) << 4) | (sl[k].cnt & 15u)) - 1;
+            }
+        }
+        out[w.dst] = o;
     }
+    stack_need += 1;  // the count above is of entries below the current node; one word of slack
 }
 
 }  // namespace rrt

@@ -73,13 +73,18 @@ struct MeshInfo {
     float qmag;     // largest |coordinate| of the grid + its largest extent: scales the traversal's rounding pad
     uint32_t wild;  // 1: a coordinate is not finite or beyond 2^60: the boxes are not used, every node is visited
 };
-// BVH2 node as the traversal reads it, 32 B (two 16-byte loads per lane and visit): both children's boxes on the
+// BVH node as the traversal reads it, 64 B (four 16-byte loads per lane and visit): up to FOUR children's boxes on the
 // mesh's 16-bit grid (lower faces rounded down, upper faces rounded up: the decoded box contains the builder's box).
-//   q[2a + c] = lo | hi << 16 of child c (0 left, 1 right) on axis a
-//   child >= 0 -> inner node (mesh-local index); child < 0 -> leaf: -(child + 1) = first triangle slot << 4 | count
+// quantise_bvh collapses the builders' binary trees into these (a node adopts its largest inner children's children), so
+// a ray takes about half as many dependent node fetches; leaves and their boxes are the binary tree's.
+//   q[4a + c] = lo | hi << 16 of child c on axis a
+//   child >= 0 -> inner node (mesh-local index); child < 0 -> leaf: -(child + 1) = first triangle slot << 4 | count;
+//   RRT_BVH_EMPTY -> no child in this slot: a leaf of no triangles whose box is inside out (lower face 65535, upper
+//   face 0), so it is never visited, and harmless when it is (wild meshes, whose boxes are not used)
+#define RRT_BVH_EMPTY ((int32_t)-1)
 struct BvhNodeQ {
-    uint32_t q[6];
-    int32_t child[2];
+    uint32_t q[12];
+    int32_t child[4];
 };
 // BVH2 node as the builders emit it (host SAH, device LBVH), 64 B: both children's boxes in f32.
 // child < 0  -> leaf: ~child = first triangle slot (mesh-local, in BVH order), count in cnt

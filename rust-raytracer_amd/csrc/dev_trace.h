@@ -35,6 +35,9 @@ __device__ __forceinline__ uint32_t mk_meta(bool entering, uint32_t instr, uint3
 #ifndef RRT_LDS_CHECK
 #define RRT_LDS_CHECK(lds, elem)
 #endif
+#ifndef RRT_LDS_CHECK_WORD  // same for the plain stack layout (argument: index of the 4-byte word)
+#define RRT_LDS_CHECK_WORD(lds, word)
+#endif
 struct Lds {
     float2 *le;  // hit-list entries: (distance, meta word) as one 8-byte element -> ds_read_b64 / ds_write_b64
     int *stack;
@@ -53,6 +56,30 @@ struct Lds {
         RRT_LDS_CHECK(*this, (e >> 1) * nthreads + tid);
         return stack[(((e >> 1) * nthreads + tid) << 1) + (e & 1u)];
     }
+    // Scenes without CSG keep nothing but traversal stacks in LDS, so the stack can be plain 4-byte words [word][lane]:
+    // the next word is one constant stride away (one add per push or pop instead of the column arithmetic above).
+    __device__ __forceinline__ int &word(uint32_t e) {
+        RRT_LDS_CHECK_WORD(*this, e * nthreads + tid);
+        return stack[e * nthreads + tid];
+    }
+};
+// the traversal stack of one lane in either layout
+template <bool PLAIN>
+struct LaneStack {
+    Lds &lds;
+    uint32_t sp;
+    __device__ __forceinline__ void push(int v) {
+        if (PLAIN)
+            lds.word(sp) = v;
+        else
+            lds.st(sp) = v;
+        sp++;
+    }
+    __device__ __forceinline__ int pop() {
+        sp--;
+        return PLAIN ? lds.word(sp) : lds.st(sp);
+    }
+    __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
 struct Counters {
@@ -232,33 +259,38 @@ __device__ __forceinline__ RaySlabs make_slabs(const MeshInfo &M, f3 o, f3 d) {
     r.bf = mk3(nx ? blo.x : bhi.x, ny ? blo.y : bhi.y, nz ? blo.z : bhi.z);
     return r;
 }
-__device__ __forceinline__ void box2_test(const BvhNodeQ &N, const RaySlabs &R, float tmax, bool &hit_l, bool &hit_r, float &near_l,
-                                          float &near_r) {
-    // grid word = lo | hi << 16; rotated by the ray's shift its LOW half is the face the ray meets first
+// one child of a node: slab distances of its box, entry (near) and whether [max(near, 0), min(far, tmax)] is not empty
+// once its far end is widened.  wx / wy / wz: the child's grid words (lo | hi << 16), rotated by the ray's shift their
+// LOW half is the face the ray meets first.
+__device__ __forceinline__ bool box_test(uint32_t wx, uint32_t wy, uint32_t wz, const RaySlabs &R, float tmax, float &near) {
 #define RRT_ROT(w, s) __builtin_amdgcn_alignbit((w), (w), (s))
 #define RRT_QN(w) ((float)((w) & 0xFFFFu))
 #define RRT_QF(w) ((float)((w) >> 16))
-    const uint32_t lx = RRT_ROT(N.q[0], R.sx), rx = RRT_ROT(N.q[1], R.sx);
-    const uint32_t ly = RRT_ROT(N.q[2], R.sy), ry = RRT_ROT(N.q[3], R.sy);
-    const uint32_t lz = RRT_ROT(N.q[4], R.sz), rz = RRT_ROT(N.q[5], R.sz);
-    const float ln = fmaxf(fmaxf(__builtin_fmaf(RRT_QN(lx), R.a.x, R.bn.x), __builtin_fmaf(RRT_QN(ly), R.a.y, R.bn.y)), __builtin_fmaf(RRT_QN(lz), R.a.z, R.bn.z));
-    const float lf = fminf(fminf(__builtin_fmaf(RRT_QF(lx), R.a.x, R.bf.x), __builtin_fmaf(RRT_QF(ly), R.a.y, R.bf.y)), __builtin_fmaf(RRT_QF(lz), R.a.z, R.bf.z));
-    const float rn = fmaxf(fmaxf(__builtin_fmaf(RRT_QN(rx), R.a.x, R.bn.x), __builtin_fmaf(RRT_QN(ry), R.a.y, R.bn.y)), __builtin_fmaf(RRT_QN(rz), R.a.z, R.bn.z));
-    const float rf = fminf(fminf(__builtin_fmaf(RRT_QF(rx), R.a.x, R.bf.x), __builtin_fmaf(RRT_QF(ry), R.a.y, R.bf.y)), __builtin_fmaf(RRT_QF(rz), R.a.z, R.bf.z));
+    const uint32_t x = RRT_ROT(wx, R.sx), y = RRT_ROT(wy, R.sy), z = RRT_ROT(wz, R.sz);
+    const float n = fmaxf(fmaxf(__builtin_fmaf(RRT_QN(x), R.a.x, R.bn.x), __builtin_fmaf(RRT_QN(y), R.a.y, R.bn.y)), __builtin_fmaf(RRT_QN(z), R.a.z, R.bn.z));
+    const float f = fminf(fminf(__builtin_fmaf(RRT_QF(x), R.a.x, R.bf.x), __builtin_fmaf(RRT_QF(y), R.a.y, R.bf.y)), __builtin_fmaf(RRT_QF(z), R.a.z, R.bf.z));
 #undef RRT_ROT
 #undef RRT_QN
 #undef RRT_QF
     const float K = 1.000003814697265625f;  // 1 + 2^-18
-    // hit: the interval [max(near, 0), min(far, tmax)] is not empty once its far end is widened
-    hit_l = lf >= 0.0f && ln <= fminf(lf, tmax) * K;
-    hit_r = rf >= 0.0f && rn <= fminf(rf, tmax) * K;
-    near_l = ln;
-    near_r = rn;
+    near = n;
+    return f >= 0.0f && n <= fminf(f, tmax) * K;
+}
+// compare-exchange of two (distance, child) pairs: afterwards a is the nearer one
+__device__ __forceinline__ void order2(float &ka, int &ca, float &kb, int &cb) {
+    const bool swap = kb < ka;
+    const float k = swap ? ka : kb;
+    const int c = swap ? ca : cb;
+    ka = swap ? kb : ka;
+    ca = swap ? cb : ca;
+    kb = k;
+    cb = c;
 }
 
 // PolyMesh::intersect (polymesh_object.rs:216-242): the closest hit of EITHER facing with t >= 0,
 // the lowest triangle index winning exact ties; only hits with t < tmax are reported (callers pass
 // the best distance so far: a farther mesh hit could not win anyway).  Returns the BVH slot.
+template <bool PLAIN_STACK = false>
 __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &M, f3 o, f3 d, float tmax, Lds &lds, Counters &cnt,
                                              float &best_t, uint32_t &best_slot, bool &best_entering) {
     const RaySlabs slabs = make_slabs(M, o, d);
@@ -271,7 +303,7 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
     const TriHot *tris = S.tris + M.tri_first;
     const uint32_t *orig = S.tri_index + M.tri_first;
     const uint32_t node_count = M.node_count, tri_count = M.tri_count;  // locals: M is memory the loop would re-read
-    int sp = 0;
+    LaneStack<PLAIN_STACK> stack{lds, 0u};
     int cur = 0;  // root
     if (tri_count == 0) return false;
     for (;;) {
@@ -280,25 +312,33 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
                 cnt.overflow |= 16u;              // RRT_ERR_BIT_INTERNAL
                 break;
             }
-            // 32 bytes per node and fewer than 2^27 nodes per mesh: the byte offset fits 32 bits, so the load can take the
+            // 64 bytes per node and fewer than 2^26 nodes per mesh: the byte offset fits 32 bits, so the load can take the
             // mesh's base from SGPRs and ONE vector register of offset (no 64-bit address arithmetic per visit)
-            const BvhNodeQ N = *reinterpret_cast<const BvhNodeQ *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)cur << 5));
-            bool hl, hr;
-            float nl, nr;
-            box2_test(N, slabs, best, hl, hr, nl, nr);
-            cnt.nodes += 2;
-            const int el = N.child[0], er = N.child[1];  // leaves: negative, first slot and count packed (BvhNodeQ)
-            if (hl && hr) {
-                bool left_first = !(nr < nl);
-                lds.st(sp++) = left_first ? er : el;
-                cur = left_first ? el : er;
-                continue;
-            } else if (hl) {
-                cur = el;
-                continue;
-            } else if (hr) {
-                cur = er;
-                continue;
+            const BvhNodeQ N = *reinterpret_cast<const BvhNodeQ *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)cur << 6));
+            int c0 = N.child[0], c1 = N.child[1], c2 = N.child[2], c3 = N.child[3];
+            float k0, k1, k2, k3;
+            const bool h0 = box_test(N.q[0], N.q[4], N.q[8], slabs, best, k0);
+            const bool h1 = box_test(N.q[1], N.q[5], N.q[9], slabs, best, k1);
+            const bool h2 = box_test(N.q[2], N.q[6], N.q[10], slabs, best, k2);
+            const bool h3 = box_test(N.q[3], N.q[7], N.q[11], slabs, best, k3);
+            cnt.nodes += 4;  // box tests executed (an empty slot's inside-out box is tested like any other)
+            if (h0 || h1 || h2 || h3) {
+                // Nearest first, the others on the stack farthest first.  A miss gets the key +inf and sorts behind every
+                // hit; what still has the key +inf afterwards is not visited (a box first met at +inf holds nothing a ray
+                // could hit before `best`).  An empty slot of a wild mesh "hits" too: its code is a leaf of no triangles.
+                k0 = h0 ? k0 : RRT_INF, k1 = h1 ? k1 : RRT_INF, k2 = h2 ? k2 : RRT_INF, k3 = h3 ? k3 : RRT_INF;
+                order2(k0, c0, k1, c1);
+                order2(k2, c2, k3, c3);
+                order2(k0, c0, k2, c2);
+                order2(k1, c1, k3, c3);
+                order2(k1, c1, k2, c2);
+                if (k3 < RRT_INF) stack.push(c3);
+                if (k2 < RRT_INF) stack.push(c2);
+                if (k1 < RRT_INF) stack.push(c1);
+                if (k0 < RRT_INF) {
+                    cur = c0;
+                    continue;
+                }
             }
         } else {
             uint32_t code = (uint32_t)(-(cur + 1));
@@ -324,8 +364,8 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
                 }
             }
         }
-        if (sp == 0) break;
-        cur = lds.st(--sp);
+        if (stack.empty()) break;
+        cur = stack.pop();
     }
     best_t = best;
     return found;
@@ -566,7 +606,7 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, const Pro
             float t;
             uint32_t slot;
             bool ent;
-            if (!mesh_closest(S, S.meshes[r.aux], o, d, mesh_bound, lds, cnt, t, slot, ent)) return false;
+            if (!mesh_closest<!(FEAT & FEAT_CSG)>(S, S.meshes[r.aux], o, d, mesh_bound, lds, cnt, t, slot, ent)) return false;
             if (!ent) return false;  // a nearer back face hides farther front faces
             t_out = t;
             sub_out = slot;

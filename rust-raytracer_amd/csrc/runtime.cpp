@@ -259,10 +259,16 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
                 build_bvh(o.tri_pos.data(), n, order, nodes, depth);
             }
             F.ms_bvh_build += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            F.bvh_depth = std::max(F.bvh_depth, depth);
-            mi.node_count = (uint32_t)nodes.size();
             std::vector<BvhNodeQ> qnodes;
-            quantise_bvh(nodes, mi, qnodes);
+            uint32_t stack_need = 0;  // traversal stack words a ray of this mesh can need (4-wide tree: more than its depth)
+            quantise_bvh(nodes, mi, qnodes, stack_need);
+            (void)depth;
+            F.bvh_depth = std::max(F.bvh_depth, stack_need);
+            if (qnodes.size() >= (1u << 26)) {  // the traversal addresses a mesh's nodes by a 32-bit byte offset
+                if (!F.error) F.error = fail(RRT_ERR_LIMIT, "a mesh with 2^26 or more BVH nodes");
+                break;
+            }
+            mi.node_count = (uint32_t)qnodes.size();
             F.nodes.insert(F.nodes.end(), qnodes.begin(), qnodes.end());
             F.tris.reserve(F.tris.size() + n);
             F.tri_index.reserve(F.tri_index.size() + n);

@@ -190,7 +190,7 @@ int render_rays(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixe
                 const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream);
 void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth);
 // bvh_build.cpp: the traversal's 32-byte nodes from either builder's output; fills the mesh's grid (qbase, qscale, qmag, wild)
-void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<BvhNodeQ> &out);
+void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<BvhNodeQ> &out, uint32_t &stack_need);
 // bvh_lbvh.hip: the same outputs from the device-side LBVH build (n > 4); device_ms = HIP-event time of its kernels
 int build_bvh_device(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
                      float *device_ms);

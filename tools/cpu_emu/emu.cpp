@@ -17,6 +17,14 @@ static size_t g_lds_elems = 0;
             abort();                                                                                                     \
         }                                                                                                                \
     } while (0)
+#define RRT_LDS_CHECK_WORD(lds, word)                                                                                    \
+    do {                                                                                                                 \
+        size_t w_ = (word);                                                                                              \
+        if (w_ >= 2 * g_lds_elems || w_ % (lds).nthreads != (lds).tid) {                                                \
+            fprintf(stderr, "LDS CHECK FAILED: word %zu (allocation %zu), lane %u of %u\n", w_, 2 * g_lds_elems, (lds).tid, (lds).nthreads); \
+            abort();                                                                                                     \
+        }                                                                                                                \
+    } while (0)
 #include "dev_trace.h"
 #include <atomic>
 #include <barrier>
@@ -155,7 +163,9 @@ int main(int argc, char **argv) {
                         f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
                         if (phase == 0) {
                             TraceResult tr;
-                            trace(S, o, d, lds, cnt, tr);
+                            // the instance the launcher would pick: scenes without CSG use the plain stack layout
+                            if (S.has_csg) trace<FEAT_ALL>(S, o, d, lds, cnt, tr);
+                            else trace<FEAT_MESH>(S, o, d, lds, cnt, tr);
                             results[i * 4] = tr.object;
                             results[i * 4 + 1] = __float_as_uint(tr.object == 0xFFFFFFFFu ? 0.0f : tr.t);
                             uint32_t prim = 0;  // as k_batch_trace computes it
@@ -176,7 +186,7 @@ int main(int argc, char **argv) {
                             }
                             results[i * 4 + 2] = prim;
                         } else {
-                            results[i * 4 + 3] = shadowtrace(S, o, d, shadow_limit, lds, cnt) ? 1u : 0u;
+                            results[i * 4 + 3] = (S.has_csg ? shadowtrace<FEAT_ALL>(S, o, d, shadow_limit, lds, cnt) : shadowtrace<FEAT_MESH>(S, o, d, shadow_limit, lds, cnt)) ? 1u : 0u;
                         }
                         wave.leave();
                         if (cnt.overflow) { std::lock_guard<std::mutex> g(om); overflow |= cnt.overflow; }
