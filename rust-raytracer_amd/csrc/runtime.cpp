@@ -628,14 +628,198 @@ void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, ui
 
 }  // namespace
 
+// What one render call carries from round to round.
+struct FrameRun {
+    rrt_scene *s;
+    const DevCamera *cam;
+    uint32_t y0, n_pixels;
+    const float *origins_dev, *directions_dev;
+    float *rgb_dev, *depth_dev;
+    uint32_t *id_dev;
+    hipStream_t stream;
+    uint32_t n_lights, depth_cap, n_levels, knn_k;
+    bool heavy_queue;
+    // results so far
+    bool lane0_clean = true;   // lane 0's counters were zeroed together with the statistics
+    bool tail_done = false;    // the frame's end event and statistics copy are already on the stream
+    uint64_t secondary = 0;
+    float ms_trace = 0.0f;
+    uint32_t err = 0;
+};
+
+static void set_level_args(FrameRun &R, TraceArgs &A, RenderLane &L, uint32_t k, uint32_t count, const uint32_t *count_ptr, uint32_t next_limit) {
+    A.cur = L.levels[k].view();
+    A.next = L.levels[k + 1].view();
+    A.count = count;
+    A.count_ptr = count_ptr;
+    A.next_limit = next_limit;
+    A.level = k;
+    A.next_count = L.ctr + (k + 1);
+    A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
+    A.heavy = L.heavy.p;
+    A.heavy_capacity = count;
+    A.knn_k = R.knn_k;
+    A.knn_ws = L.knn.p;
+    A.knn_stride = count;
+}
+
+// One round of chunks launched for the level sizes of the previous frame: no readback between launches, one sync at the
+// end.  overflow: a queue outgrew its launch, nothing was written past it, the caller repeats the frame level by level.
+static int run_round_predicted(FrameRun &R, std::vector<ChunkPlan> &plan, uint32_t round, bool last_round, bool &overflow) {
+    rrt_scene *s = R.s;
+    DeviceScene &D = s->dev;
+    hipStream_t stream = R.stream;
+    const uint32_t n_levels = R.n_levels;
+    int rc;
+    overflow = false;
+    if (plan.size() > 1) {  // fork: the other lanes start after what the caller's stream holds so far
+        RRT_HIP(hipEventRecord(s->events[2], stream));
+        for (size_t j = 1; j < plan.size(); j++) RRT_HIP(hipStreamWaitEvent(s->lanes[j]->stream, s->events[2], 0));
+    }
+    for (size_t j = 0; j < plan.size(); j++) {
+        RenderLane &L = *s->lanes[j];
+        hipStream_t st = j == 0 ? stream : L.stream;
+        const std::vector<uint32_t> &pred = L.prediction[round];
+        std::vector<uint32_t> caps(n_levels + 1, 0);
+        caps[0] = plan[j].n;
+        // Levels the previous frame left empty are not launched at all (a photon-mapped frame of scene2 has rays on 2
+        // of its 13 levels): the last launched level gets next_limit 0, so a ray that does want to go deeper raises
+        // RRT_ERR_BIT_QUEUE and the frame is repeated level by level, like any other outgrown prediction.
+        uint32_t n_run = n_levels;
+        for (uint32_t k = 1; k < n_levels; k++)
+            if (pred[1 + k] == 0) {
+                n_run = k;
+                break;
+            }
+        if ((rc = L.levels[0].ensure(plan[j].n, R.n_lights, R.cam == nullptr))) return rc;
+        for (uint32_t k = 1; k < n_run; k++) {
+            uint64_t want = (uint64_t)pred[1 + k] + pred[1 + k] / 8 + 4096;
+            caps[k] = (uint32_t)std::min<uint64_t>(want, 2ull * caps[k - 1]);
+            if ((rc = L.levels[k].ensure(caps[k], R.n_lights, true))) return rc;
+        }
+        if ((rc = L.levels[n_run].ensure(1, R.n_lights, true))) return rc;
+        const uint32_t widest = *std::max_element(caps.begin(), caps.end());
+        if (R.heavy_queue && (rc = L.heavy.ensure(widest))) return rc;
+        if (R.knn_k && (rc = L.knn.ensure((size_t)R.knn_k * widest))) return rc;
+        if (!(j == 0 && R.lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), st));
+        if (j == 0) R.lane0_clean = false;
+        if (!R.cam)
+            launch_load_rays(R.origins_dev + (size_t)plan[j].base * 3, R.directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), st);
+        TraceArgs A;
+        fill_args(s, A, R.cam, R.y0, R.n_pixels, plan[j].base, R.depth_cap, L, R.rgb_dev, R.depth_dev, R.id_dev);
+        RRT_HIP(hipEventRecord(L.ev_trace0, st));
+        for (uint32_t k = 0; k < n_run; k++) {
+            set_level_args(R, A, L, k, caps[k], k ? L.ctr + k : nullptr, caps[k + 1]);  // next_limit 0 behind the last launched level
+            launch_trace_shade(A, D.lds_bytes, st);
+            launch_gather_heavy(A, st);
+        }
+        RRT_HIP(hipEventRecord(L.ev_trace1, st));
+        for (int k = (int)n_run - 1; k >= 0 && !A.fuse; k--) {
+            set_level_args(R, A, L, (uint32_t)k, caps[k], k ? L.ctr + k : nullptr, 0);
+            launch_combine(A, st);
+        }
+        const bool one_copy = plan.size() == 1 && last_round;  // statistics + counters in one go below
+        if (!one_copy) RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (j > 0) {  // join
+            RRT_HIP(hipEventRecord(L.ev_done, st));
+            RRT_HIP(hipStreamWaitEvent(stream, L.ev_done, 0));
+        }
+    }
+    if (last_round) {  // the frame's end event and the stats ride on the same sync
+        unsigned long long *st_all = reinterpret_cast<unsigned long long *>(s->host_pinned);
+        RRT_HIP(hipEventRecord(s->events[1], stream));
+        RRT_HIP(hipMemcpyAsync(st_all, s->stats_dev.p, (RRT_STAT_WORDS + (plan.size() == 1 ? 32 : 0)) * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, stream));
+        R.tail_done = true;
+    }
+    RRT_HIP(hipStreamSynchronize(stream));
+    for (size_t j = 0; j < plan.size(); j++) overflow |= (s->lanes[j]->host_pinned[63] & RRT_ERR_BIT_QUEUE) != 0;
+    if (overflow) return RRT_OK;
+    float first = 0.0f, last = 0.0f;  // wall-clock span of the trace launches of this round
+    for (size_t j = 0; j < plan.size(); j++) {
+        RenderLane &L = *s->lanes[j];
+        R.err |= L.host_pinned[63];
+        for (uint32_t k = 1; k < n_levels; k++) {
+            plan[j].counts[k] = L.host_pinned[k];
+            R.secondary += L.host_pinned[k];
+        }
+        float t0 = 0.0f, t1 = 0.0f;
+        RRT_HIP(hipEventElapsedTime(&t0, s->events[0], L.ev_trace0));
+        RRT_HIP(hipEventElapsedTime(&t1, s->events[0], L.ev_trace1));
+        first = j == 0 ? t0 : std::min(first, t0);
+        last = j == 0 ? t1 : std::max(last, t1);
+    }
+    R.ms_trace += last - first;
+    return RRT_OK;
+}
+
+// One round of chunks level by level, one chunk after the other, on the caller's stream: every level's size is read
+// back before the next one is launched (the first frame of a size, and frames that outgrew their prediction).
+static int run_round_by_level(FrameRun &R, std::vector<ChunkPlan> &plan) {
+    rrt_scene *s = R.s;
+    DeviceScene &D = s->dev;
+    hipStream_t stream = R.stream;
+    const uint32_t n_levels = R.n_levels;
+    int rc;
+    for (size_t j = 0; j < plan.size(); j++) {
+        RenderLane &L = *s->lanes[j];
+        std::vector<uint32_t> &counts = plan[j].counts;
+        if ((rc = L.levels[0].ensure(plan[j].n, R.n_lights, R.cam == nullptr))) return rc;
+        if (!(j == 0 && R.lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), stream));
+        if (j == 0) R.lane0_clean = false;
+        if (!R.cam)
+            launch_load_rays(R.origins_dev + (size_t)plan[j].base * 3, R.directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), stream);
+        TraceArgs A;
+        fill_args(s, A, R.cam, R.y0, R.n_pixels, plan[j].base, R.depth_cap, L, R.rgb_dev, R.depth_dev, R.id_dev);
+        uint32_t last = 0;
+        for (uint32_t k = 0; k < n_levels; k++) {
+            bool spawns = k + 1 < n_levels;
+            if (spawns && (rc = L.levels[k + 1].ensure(2 * counts[k], R.n_lights, true))) return rc;
+            // the stream is idle here (synchronised after the previous level): growing the per-level buffers is safe
+            if (R.heavy_queue && (rc = L.heavy.ensure(counts[k]))) return rc;
+            if (R.knn_k && (rc = L.knn.ensure((size_t)R.knn_k * counts[k]))) return rc;
+            set_level_args(R, A, L, k, counts[k], nullptr, spawns ? 2 * counts[k] : 0);
+            RRT_HIP(hipEventRecord(L.ev_trace0, stream));
+            launch_trace_shade(A, D.lds_bytes, stream);
+            launch_gather_heavy(A, stream);
+            RRT_HIP(hipEventRecord(L.ev_trace1, stream));
+            last = k;
+            uint32_t next_n = 0;
+            if (spawns) {
+                RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                RRT_HIP(hipStreamSynchronize(stream));
+                next_n = L.host_pinned[0];
+            } else {
+                RRT_HIP(hipStreamSynchronize(stream));
+            }
+            float ms = 0.0f;
+            RRT_HIP(hipEventElapsedTime(&ms, L.ev_trace0, L.ev_trace1));
+            R.ms_trace += ms;
+            counts[k + 1] = next_n;
+            R.secondary += next_n;
+            if (next_n == 0) break;
+        }
+        for (int k = (int)last; k >= 0 && !A.fuse; k--) {
+            set_level_args(R, A, L, (uint32_t)k, counts[k], nullptr, 0);
+            launch_combine(A, stream);
+        }
+        RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr + 63, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        RRT_HIP(hipStreamSynchronize(stream));
+        R.err |= L.host_pinned[0];
+    }
+    return RRT_OK;
+}
+
 static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, const float *origins_dev,
                             const float *directions_dev, float *rgb_dev, float *depth_dev, uint32_t *id_dev, hipStream_t stream,
                             bool allow_predicted, bool &retry) {
     retry = false;
     DeviceScene &D = s->dev;
-    const uint32_t n_lights = D.view.n_lights;
-    const uint32_t depth_cap = s->mode == RRT_MODE_SCENE ? s->params.max_depth : s->params.max_vueon_depth;
-    const uint32_t n_levels = D.reflective ? depth_cap + 1 : 1;
+    FrameRun R{s, cam, y0, n_pixels, origins_dev, directions_dev, rgb_dev, depth_dev, id_dev, stream};
+    R.n_lights = D.view.n_lights;
+    R.depth_cap = s->mode == RRT_MODE_SCENE ? s->params.max_depth : s->params.max_vueon_depth;
+    R.n_levels = D.reflective ? R.depth_cap + 1 : 1;
+    const uint32_t n_levels = R.n_levels;
     if (n_levels + 2 > 60) return fail(RRT_ERR_LIMIT, "recursion depth above 57");
     int rc;
     uint32_t want_lanes = s->params.render_streams ? std::min(s->params.render_streams, 8u) : 1u;
@@ -643,9 +827,9 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     uint32_t chunk = s->params.chunk_pixels ? s->params.chunk_pixels : (1u << 23);  // a 3840x2160 frame is one chunk
     // photon mode with the k-nearest estimator (get_n_within_radius): every ray in flight owns gather_k heap entries of 8
     // bytes; chunks shrink so that a level of chunk size stays under 2 GiB of them
-    const uint32_t knn_k = s->mode == RRT_MODE_PHOTON ? s->params.gather_k : 0u;
-    if (knn_k > RRT_GATHER_K_MAX) return fail(RRT_ERR_LIMIT, "gather_k above RRT_GATHER_K_MAX (4096)");
-    if (knn_k) chunk = std::min(chunk, std::max(1u << 16, ((1u << 28) / knn_k) & ~255u));
+    R.knn_k = s->mode == RRT_MODE_PHOTON ? s->params.gather_k : 0u;
+    if (R.knn_k > RRT_GATHER_K_MAX) return fail(RRT_ERR_LIMIT, "gather_k above RRT_GATHER_K_MAX (4096)");
+    if (R.knn_k) chunk = std::min(chunk, std::max(1u << 16, ((1u << 28) / R.knn_k) & ~255u));
     if (want_lanes > 1 && n_pixels >= (1u << 18)) {  // big enough to be worth cutting: one chunk per lane, whole waves
         uint32_t per_lane = (n_pixels + want_lanes - 1) / want_lanes;
         per_lane = (per_lane + 255u) & ~255u;
@@ -656,25 +840,20 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     if ((rc = ensure_lanes(s, want_lanes))) return rc;
     for (uint32_t j = 0; j < want_lanes; j++)
         if (s->lanes[j]->levels.size() < n_levels + 1) s->lanes[j]->levels.resize(n_levels + 1);
-    // photon mode: heavy radiance estimates are filed per level (lane counters [32 + level]) and gathered by whole waves
-    const bool heavy_queue = s->mode == RRT_MODE_PHOTON && s->params.gather_heavy_threshold != 0xFFFFFFFFu && n_levels <= 30 && !knn_k;
+    // photon mode: heavy radiance estimates are filed per level (lane counters [32 + level]) and gathered by whole waves.
     // The queue of a level holds one record per ray of that level (every query may be heavy), so it is sized from the
-    // level sizes below, never from the chunk: a level behind glass can hold more rays than the chunk has pixels, and a
-    // lane that found the queue full would gather for itself in another summation order (frames would then depend on
-    // atomics order).
-    if (!heavy_queue)
-        for (uint32_t j = 0; j < want_lanes; j++) s->lanes[j]->heavy.release();
-    if (!knn_k)
-        for (uint32_t j = 0; j < want_lanes; j++) s->lanes[j]->knn.release();
+    // level sizes, never from the chunk: a level behind glass can hold more rays than the chunk has pixels, and a lane
+    // that found the queue full would gather for itself in another summation order (frames would then depend on atomics
+    // order).
+    R.heavy_queue = s->mode == RRT_MODE_PHOTON && s->params.gather_heavy_threshold != 0xFFFFFFFFu && n_levels <= 30 && !R.knn_k;
+    for (uint32_t j = 0; j < want_lanes; j++) {
+        if (!R.heavy_queue) s->lanes[j]->heavy.release();
+        if (!R.knn_k) s->lanes[j]->knn.release();
+    }
 
     RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, (RRT_STAT_WORDS + 32) * sizeof(unsigned long long), stream));  // + lane 0's counters
-    bool lane0_clean = true;
     RRT_HIP(hipEventRecord(s->events[0], stream));
-    uint64_t secondary = 0;
-    float ms_trace = 0.0f;
-    uint32_t err = 0;
     unsigned long long *st_all = reinterpret_cast<unsigned long long *>(s->host_pinned);  // RRT_STAT_WORDS slots
-    bool tail_done = false;
 
     uint32_t round = 0;
     static const std::vector<uint32_t> no_prediction;
@@ -697,179 +876,26 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
             if (!(pred.size() == n_levels + 2 && pred[0] == plan[j].n)) predicted = false;
         }
         if (predicted) {
-            if (plan.size() > 1) {  // fork: the other lanes start after what the caller's stream holds so far
-                RRT_HIP(hipEventRecord(s->events[2], stream));
-                for (size_t j = 1; j < plan.size(); j++) RRT_HIP(hipStreamWaitEvent(s->lanes[j]->stream, s->events[2], 0));
-            }
-            for (size_t j = 0; j < plan.size(); j++) {
-                RenderLane &L = *s->lanes[j];
-                hipStream_t st = j == 0 ? stream : L.stream;
-                const std::vector<uint32_t> &pred = L.prediction[round];
-                std::vector<uint32_t> caps(n_levels + 1, 0);
-                caps[0] = plan[j].n;
-                // Levels the previous frame left empty are not launched at all (a photon-mapped frame of scene2 has rays on 2
-                // of its 13 levels): the last launched level gets next_limit 0, so a ray that does want to go deeper raises
-                // RRT_ERR_BIT_QUEUE and the frame is repeated level by level, like any other outgrown prediction.
-                uint32_t n_run = n_levels;
-                for (uint32_t k = 1; k < n_levels; k++)
-                    if (pred[1 + k] == 0) {
-                        n_run = k;
-                        break;
-                    }
-                if ((rc = L.levels[0].ensure(plan[j].n, n_lights, cam == nullptr))) return rc;
-                for (uint32_t k = 1; k < n_run; k++) {
-                    uint64_t want = (uint64_t)pred[1 + k] + pred[1 + k] / 8 + 4096;
-                    caps[k] = (uint32_t)std::min<uint64_t>(want, 2ull * caps[k - 1]);
-                    if ((rc = L.levels[k].ensure(caps[k], n_lights, true))) return rc;
-                }
-                if ((rc = L.levels[n_run].ensure(1, n_lights, true))) return rc;
-                if (heavy_queue && (rc = L.heavy.ensure(*std::max_element(caps.begin(), caps.end())))) return rc;
-                if (knn_k && (rc = L.knn.ensure((size_t)knn_k * *std::max_element(caps.begin(), caps.end())))) return rc;
-                if (!(j == 0 && lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), st));
-                if (j == 0) lane0_clean = false;
-                if (!cam)
-                    launch_load_rays(origins_dev + (size_t)plan[j].base * 3, directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), st);
-                TraceArgs A;
-                fill_args(s, A, cam, y0, n_pixels, plan[j].base, depth_cap, L, rgb_dev, depth_dev, id_dev);
-                RRT_HIP(hipEventRecord(L.ev_trace0, st));
-                for (uint32_t k = 0; k < n_run; k++) {
-                    A.cur = L.levels[k].view();
-                    A.next = L.levels[k + 1].view();
-                    A.count = caps[k];
-                    A.count_ptr = k ? L.ctr + k : nullptr;
-                    A.next_limit = caps[k + 1];  // 0 behind the last launched level
-                    A.level = k;
-                    A.next_count = L.ctr + (k + 1);
-                    A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
-                    A.heavy_capacity = caps[k];
-                    A.knn_k = knn_k;
-                    A.knn_ws = L.knn.p;
-                    A.knn_stride = caps[k];
-                    launch_trace_shade(A, D.lds_bytes, st);
-                    launch_gather_heavy(A, st);
-                }
-                RRT_HIP(hipEventRecord(L.ev_trace1, st));
-                for (int k = (int)n_run - 1; k >= 0 && !A.fuse; k--) {
-                    A.cur = L.levels[k].view();
-                    A.next = L.levels[k + 1].view();
-                    A.count = caps[k];
-                    A.count_ptr = k ? L.ctr + k : nullptr;
-                    A.level = (uint32_t)k;
-                    launch_combine(A, st);
-                }
-                const bool one_copy = plan.size() == 1 && round_base >= n_pixels;  // statistics + counters in one go below
-                if (!one_copy) RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                if (j > 0) {  // join
-                    RRT_HIP(hipEventRecord(L.ev_done, st));
-                    RRT_HIP(hipStreamWaitEvent(stream, L.ev_done, 0));
-                }
-            }
-            if (round_base >= n_pixels) {  // last round: the frame's end event and the stats ride on the same sync
-                RRT_HIP(hipEventRecord(s->events[1], stream));
-                RRT_HIP(hipMemcpyAsync(st_all, s->stats_dev.p, (RRT_STAT_WORDS + (plan.size() == 1 ? 32 : 0)) * sizeof(unsigned long long),
-                                       hipMemcpyDeviceToHost, stream));
-                tail_done = true;
-            }
-            RRT_HIP(hipStreamSynchronize(stream));
             bool overflow = false;
-            for (size_t j = 0; j < plan.size(); j++) overflow |= (s->lanes[j]->host_pinned[63] & RRT_ERR_BIT_QUEUE) != 0;
+            if ((rc = run_round_predicted(R, plan, round, round_base >= n_pixels, overflow))) return rc;
             if (overflow) {
                 for (auto &L : s->lanes) L->prediction.clear();
                 retry = true;
                 return RRT_OK;
             }
-            float first = 0.0f, last = 0.0f;  // wall-clock span of the trace launches of this round
-            for (size_t j = 0; j < plan.size(); j++) {
-                RenderLane &L = *s->lanes[j];
-                err |= L.host_pinned[63];
-                for (uint32_t k = 1; k < n_levels; k++) {
-                    plan[j].counts[k] = L.host_pinned[k];
-                    secondary += L.host_pinned[k];
-                }
-                float t0 = 0.0f, t1 = 0.0f;
-                RRT_HIP(hipEventElapsedTime(&t0, s->events[0], L.ev_trace0));
-                RRT_HIP(hipEventElapsedTime(&t1, s->events[0], L.ev_trace1));
-                first = j == 0 ? t0 : std::min(first, t0);
-                last = j == 0 ? t1 : std::max(last, t1);
-            }
-            ms_trace += last - first;
-        } else {  // level by level, one chunk after the other, on the caller's stream
-            for (size_t j = 0; j < plan.size(); j++) {
-                RenderLane &L = *s->lanes[j];
-                std::vector<uint32_t> &counts = plan[j].counts;
-                if ((rc = L.levels[0].ensure(plan[j].n, n_lights, cam == nullptr))) return rc;
-                if (!(j == 0 && lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), stream));
-                if (j == 0) lane0_clean = false;
-                if (!cam)
-                    launch_load_rays(origins_dev + (size_t)plan[j].base * 3, directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), stream);
-                TraceArgs A;
-                fill_args(s, A, cam, y0, n_pixels, plan[j].base, depth_cap, L, rgb_dev, depth_dev, id_dev);
-                uint32_t last = 0;
-                for (uint32_t k = 0; k < n_levels; k++) {
-                    bool spawns = k + 1 < n_levels;
-                    if (spawns && (rc = L.levels[k + 1].ensure(2 * counts[k], n_lights, true))) return rc;
-                    if (heavy_queue) {  // the stream is idle here (synchronised after the previous level): growing is safe
-                        if ((rc = L.heavy.ensure(counts[k]))) return rc;
-                        A.heavy = L.heavy.p;
-                        A.heavy_capacity = counts[k];
-                    }
-                    if (knn_k) {  // same here
-                        if ((rc = L.knn.ensure((size_t)knn_k * counts[k]))) return rc;
-                        A.knn_k = knn_k;
-                        A.knn_ws = L.knn.p;
-                        A.knn_stride = counts[k];
-                    }
-                    A.cur = L.levels[k].view();
-                    A.next = L.levels[k + 1].view();
-                    A.count = counts[k];
-                    A.count_ptr = nullptr;
-                    A.next_limit = spawns ? 2 * counts[k] : 0;
-                    A.level = k;
-                    A.next_count = L.ctr + (k + 1);
-                    A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
-                    RRT_HIP(hipEventRecord(L.ev_trace0, stream));
-                    launch_trace_shade(A, D.lds_bytes, stream);
-                    launch_gather_heavy(A, stream);
-                    RRT_HIP(hipEventRecord(L.ev_trace1, stream));
-                    last = k;
-                    uint32_t next_n = 0;
-                    if (spawns) {
-                        RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                        RRT_HIP(hipStreamSynchronize(stream));
-                        next_n = L.host_pinned[0];
-                    } else {
-                        RRT_HIP(hipStreamSynchronize(stream));
-                    }
-                    float ms = 0.0f;
-                    RRT_HIP(hipEventElapsedTime(&ms, L.ev_trace0, L.ev_trace1));
-                    ms_trace += ms;
-                    counts[k + 1] = next_n;
-                    secondary += next_n;
-                    if (next_n == 0) break;
-                }
-                for (int k = (int)last; k >= 0 && !A.fuse; k--) {
-                    A.cur = L.levels[k].view();
-                    A.next = L.levels[k + 1].view();
-                    A.count = counts[k];
-                    A.count_ptr = nullptr;
-                    A.level = (uint32_t)k;
-                    launch_combine(A, stream);
-                }
-                RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr + 63, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                RRT_HIP(hipStreamSynchronize(stream));
-                err |= L.host_pinned[0];
-            }
+        } else {
+            if ((rc = run_round_by_level(R, plan))) return rc;
         }
         // what the next frame's chunks of these sizes will be launched for
-            for (size_t j = 0; j < plan.size(); j++) {
-                if (s->lanes[j]->prediction.size() <= round) s->lanes[j]->prediction.resize(round + 1);
-                std::vector<uint32_t> &pred = s->lanes[j]->prediction[round];
-                pred.assign(n_levels + 2, 0);
-                pred[0] = plan[j].n;
-                for (uint32_t k = 0; k <= n_levels; k++) pred[1 + k] = plan[j].counts[k];
-            }
+        for (size_t j = 0; j < plan.size(); j++) {
+            if (s->lanes[j]->prediction.size() <= round) s->lanes[j]->prediction.resize(round + 1);
+            std::vector<uint32_t> &pred = s->lanes[j]->prediction[round];
+            pred.assign(n_levels + 2, 0);
+            pred[0] = plan[j].n;
+            for (uint32_t k = 0; k <= n_levels; k++) pred[1 + k] = plan[j].counts[k];
+        }
     }
-    if (!tail_done) {
+    if (!R.tail_done) {
         RRT_HIP(hipEventRecord(s->events[1], stream));
         RRT_HIP(hipMemcpyAsync(st_all, s->stats_dev.p, RRT_STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         RRT_HIP(hipStreamSynchronize(stream));
@@ -881,22 +907,22 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     }
     float ms_total = 0.0f;
     RRT_HIP(hipEventElapsedTime(&ms_total, s->events[0], s->events[1]));
-    rrt_stats &R = s->render_stats;
-    R.rays_primary = n_pixels;
-    R.rays_secondary = secondary;
-    R.rays_shadow = st[ST_SHADOW];
-    R.bvh_nodes_visited = st[ST_NODES];
-    R.bvh_tris_tested = st[ST_TRIS];
-    R.photons_gathered = st[ST_GATHERED];
-    R.gather_queries = st[ST_QUERIES];
-    R.gather_candidates = st[ST_CANDIDATES];
-    R.flops_per_trace = D.flops_per_trace;
-    R.flops_algorithmic = (R.rays_primary + R.rays_secondary + R.rays_shadow) * D.flops_per_trace + 27ull * st[ST_NODES] + 61ull * st[ST_TRIS];
-    R.ms_trace_kernels = ms_trace;
-    R.ms_total = ms_total;
-    if (err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");
-    if (err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
-    if (err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
+    rrt_stats &O = s->render_stats;
+    O.rays_primary = n_pixels;
+    O.rays_secondary = R.secondary;
+    O.rays_shadow = st[ST_SHADOW];
+    O.bvh_nodes_visited = st[ST_NODES];
+    O.bvh_tris_tested = st[ST_TRIS];
+    O.photons_gathered = st[ST_GATHERED];
+    O.gather_queries = st[ST_QUERIES];
+    O.gather_candidates = st[ST_CANDIDATES];
+    O.flops_per_trace = D.flops_per_trace;
+    O.flops_algorithmic = (O.rays_primary + O.rays_secondary + O.rays_shadow) * D.flops_per_trace + 27ull * st[ST_NODES] + 61ull * st[ST_TRIS];
+    O.ms_trace_kernels = R.ms_trace;
+    O.ms_total = ms_total;
+    if (R.err & RRT_ERR_BIT_INTERNAL) return fail(RRT_ERR_DEVICE, "device-side index guard tripped (internal error)");
+    if (R.err & 1u) return fail(RRT_ERR_OVERFLOW, "HitVec overflow");
+    if (R.err & 2u) return fail(RRT_ERR_INVALID, "No texture coordinates");
     return RRT_OK;
 }
 
