@@ -9,6 +9,8 @@
 #include <cmath>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "dev_scene.h"
@@ -77,32 +79,24 @@ void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order,
         for (int c = 0; c < 3; c++) tb[i].grow_pt(positions + (size_t)i * 9 + c * 3);
         for (int a = 0; a < 3; a++) cen[(size_t)i * 3 + a] = 0.5f * (tb[i].lo[a] + tb[i].hi[a]);
     }
-    std::vector<TmpNode> tmp;
-    tmp.reserve(n ? 2 * (size_t)n / 2 + 16 : 16);
     struct Work {
         int node;
         uint32_t lo, hi, depth;
     };
-    std::vector<Work> stack;
     auto range_box = [&](uint32_t lo, uint32_t hi) {
         Box b;
         b.reset();
         for (uint32_t i = lo; i < hi; i++) b.grow(tb[order[i]]);
         return b;
     };
-    tmp.push_back(TmpNode());
-    tmp[0].box = range_box(0, n);
-    stack.push_back({0, 0, n, 1});
-    max_depth = 1;
-    while (!stack.empty()) {
-        Work w = stack.back();
-        stack.pop_back();
-        max_depth = std::max(max_depth, w.depth);
+    // One split: either makes pool[w.node] a leaf or partitions order[w.lo, w.hi) (nobody else's part of `order`), appends
+    // the two children to `pool` and returns their work items.
+    auto split = [&](std::vector<TmpNode> &pool, const Work &w, Work out[2]) -> bool {
         uint32_t cnt = w.hi - w.lo;
         if (cnt <= kLeafMax) {
-            tmp[w.node].first = w.lo;
-            tmp[w.node].count = cnt;
-            continue;
+            pool[w.node].first = w.lo;
+            pool[w.node].count = cnt;
+            return false;
         }
         // centroid bounds
         Box cb;
@@ -164,15 +158,83 @@ void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order,
             mid = (uint32_t)(it - order.begin());
             if (mid == w.lo || mid == w.hi) mid = w.lo + cnt / 2;
         }
-        int l = (int)tmp.size();
-        tmp.push_back(TmpNode());
-        tmp.push_back(TmpNode());
-        tmp[l].box = range_box(w.lo, mid);
-        tmp[l + 1].box = range_box(mid, w.hi);
-        tmp[w.node].left = l;
-        tmp[w.node].right = l + 1;
-        stack.push_back({l, w.lo, mid, w.depth + 1});
-        stack.push_back({l + 1, mid, w.hi, w.depth + 1});
+        int l = (int)pool.size();
+        pool.push_back(TmpNode());
+        pool.push_back(TmpNode());
+        pool[l].box = range_box(w.lo, mid);
+        pool[l + 1].box = range_box(mid, w.hi);
+        pool[w.node].left = l;
+        pool[w.node].right = l + 1;
+        out[0] = {l, w.lo, mid, w.depth + 1};
+        out[1] = {l + 1, mid, w.hi, w.depth + 1};
+        return true;
+    };
+    std::vector<TmpNode> tmp;
+    tmp.reserve(n ? (size_t)n + 16 : 16);
+    tmp.push_back(TmpNode());
+    tmp[0].box = range_box(0, n);
+    max_depth = 1;
+    // The top of the tree serially, down to sub-ranges of at most n / 16 triangles; those are independent jobs (disjoint
+    // parts of `order`, node pools of their own) and run on host threads.  The tree is the one a serial build makes.
+    const uint32_t job_size = std::max<uint32_t>(n / 16, 4096);
+    std::vector<Work> stack, jobs;
+    stack.push_back({0, 0, n, 1});
+    while (!stack.empty()) {
+        Work w = stack.back();
+        stack.pop_back();
+        max_depth = std::max(max_depth, w.depth);
+        if (w.hi - w.lo <= job_size && w.hi - w.lo > kLeafMax && n > 2 * job_size) {
+            jobs.push_back(w);
+            continue;
+        }
+        Work out[2];
+        if (split(tmp, w, out)) {
+            stack.push_back(out[0]);
+            stack.push_back(out[1]);
+        }
+    }
+    if (!jobs.empty()) {
+        std::vector<std::vector<TmpNode>> pools(jobs.size());
+        std::vector<uint32_t> depths(jobs.size(), 1);
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= jobs.size()) return;
+                std::vector<TmpNode> &pool = pools[k];
+                pool.reserve((size_t)(jobs[k].hi - jobs[k].lo) + 16);
+                pool.push_back(tmp[jobs[k].node]);  // local index 0 = the job's root
+                std::vector<Work> st;
+                st.push_back({0, jobs[k].lo, jobs[k].hi, jobs[k].depth});
+                while (!st.empty()) {
+                    Work w = st.back();
+                    st.pop_back();
+                    depths[k] = std::max(depths[k], w.depth);
+                    Work out[2];
+                    if (split(pool, w, out)) {
+                        st.push_back(out[0]);
+                        st.push_back(out[1]);
+                    }
+                }
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_threads = std::min<size_t>(std::min<size_t>(hw ? hw : 4, 16), jobs.size());
+        std::vector<std::thread> threads;
+        for (size_t t = 1; t < n_threads; t++) threads.emplace_back(worker);
+        worker();
+        for (auto &t : threads) t.join();
+        for (size_t k = 0; k < jobs.size(); k++) {  // splice the pools in: local index i > 0 becomes offset + i - 1
+            const std::vector<TmpNode> &pool = pools[k];
+            const int offset = (int)tmp.size();
+            auto fix = [&](TmpNode t) {
+                if (t.left >= 0) t.left += offset - 1, t.right += offset - 1;
+                return t;
+            };
+            tmp[jobs[k].node] = fix(pool[0]);
+            for (size_t i = 1; i < pool.size(); i++) tmp.push_back(fix(pool[i]));
+            max_depth = std::max(max_depth, depths[k]);
+        }
     }
     // leaves keep ascending original order inside a leaf (cheap tie handling, better locality)
     for (const TmpNode &t : tmp)
