@@ -1,8 +1,8 @@
 // dev_photon.h — counter-based RNG streams, the photon index and the radiance-estimate gather.
 //
 // Replaces core/photon_tree.rs (third-party kd-tree 0.5.1, `within` = closed axis-aligned box) with
-// a dense uniform grid (cell edge = half_width) over the region that holds the photons, plus a hash
-// grid for the few that lie outside it.  Records are sorted by cell so a query streams contiguous runs.
+// dense uniform grids (cell edge = half_width) over the regions that hold the photons, plus a hash
+// grid for the few that lie outside them.  Records are sorted by cell so a query streams contiguous runs.
 #pragma once
 #include "kernels.h"
 
@@ -88,14 +88,19 @@ struct GatherSums {
     uint32_t inside;  // gather_knn only: photons inside the closed box before the truncation to k
 };
 
-// ---- the index: a dense grid where the photons are, a hash grid for the stragglers ---------------------------------
-// Dense part: cells of edge r (the query half width) over the box that holds all but the outermost photons (the
-// reference's infinite planes catch photons millions of units out).  Records are sorted by cell with x running fastest,
-// so the cells a query box [p - r, p + r] overlaps along x (3, rarely 4) are ONE contiguous run of records per (y, z) row:
-// 9 runs per query, each found with two loads from the start table at computed addresses — no probing — and the records
-// read cover 3 x 3 x 3 cells of edge r instead of 2 x 2 x 2 cells of edge 2r (2.25 x instead of 4 x the query's own area
-// on a surface).  Outliers: the hash grid of round 1 (cell edge 2r, open addressing), consulted only by queries whose box
-// leaves the dense region.
+// ---- the index: dense grids where the photons are, a hash grid for the stragglers ---------------------------------
+// Dense part: cells of edge r (the query half width).  Records are sorted by cell with x running fastest, so the cells a
+// query box [p - r, p + r] overlaps along x (3, rarely 4) are ONE contiguous run of records per (y, z) row: 9 runs per
+// query, each found with two loads from the start table at computed addresses — no probing — and the records read cover
+// 3 x 3 x 3 cells of edge r instead of 2 x 2 x 2 cells of edge 2r (2.25 x instead of 4 x the query's own area on a surface).
+// Photon maps are mostly surfaces in a large volume, and a 3-D grid pays for the volume: ONE box over everything would
+// need billions of cells.  So there are up to RRT_DENSE_GRIDS boxes, each sized to a cell budget: the first around the
+// densest part of the map, every further one around the densest part of what the earlier ones left out (typically a thin
+// slab along the floor, then the walls).  A record belongs to the FIRST grid whose box holds its position.  A query walks
+// the grids in order and stops at the first one whose box holds the whole query box: every record inside the query box
+// lies in that grid's box too, hence in it or in an earlier one.  Stragglers (the reference's infinite planes catch photons
+// millions of units out): the hash grid of round 1 (cell edge 2r, open addressing), asked only by queries that no grid
+// box holds completely.
 
 // cell key -> (first record, count) through the open-addressing table of the outliers
 __device__ __forceinline__ uint2 lookup_cell(const DevPhotonMap &G, uint64_t key) {
@@ -111,29 +116,41 @@ __device__ __forceinline__ uint2 lookup_cell(const DevPhotonMap &G, uint64_t key
 // dense cell coordinate along one axis as a float (NaN for NaN input): the same function files records and places queries
 RRT_HD float dense_coord(float x, float lo, float inv_cell) { return floorf((x - lo) * inv_cell); }
 
-// The dense cells a box overlaps: [x0, x1] x [y0, y1] x [z0, z1] clamped to the grid (empty when x1 < x0 ...), and whether
-// the box reaches outside the grid (then the outliers' hash grid has to be asked as well).
+// The cells of one grid a box overlaps: [x0, x1] x [y0, y1] x [z0, z1] clamped to the grid (empty when x1 < x0 ...), and
+// whether the box reaches outside the grid (then later grids and the outliers have to be asked as well).
 struct DenseBox {
     int x0, x1, y0, y1, z0, z1;
     bool outside, empty;
 };
-__device__ __forceinline__ DenseBox dense_box(const DevPhotonMap &G, f3 lo, f3 hi) {
+__device__ __forceinline__ DenseBox dense_box(const DenseGrid &D, float inv_dcell, f3 lo, f3 hi) {
     DenseBox B;
-    const float fx0 = dense_coord(lo.x, G.dlo_x, G.inv_dcell), fx1 = dense_coord(hi.x, G.dlo_x, G.inv_dcell);
-    const float fy0 = dense_coord(lo.y, G.dlo_y, G.inv_dcell), fy1 = dense_coord(hi.y, G.dlo_y, G.inv_dcell);
-    const float fz0 = dense_coord(lo.z, G.dlo_z, G.inv_dcell), fz1 = dense_coord(hi.z, G.dlo_z, G.inv_dcell);
-    const float nx = (float)G.nx, ny = (float)G.ny, nz = (float)G.nz;
+    const float fx0 = dense_coord(lo.x, D.lo_x, inv_dcell), fx1 = dense_coord(hi.x, D.lo_x, inv_dcell);
+    const float fy0 = dense_coord(lo.y, D.lo_y, inv_dcell), fy1 = dense_coord(hi.y, D.lo_y, inv_dcell);
+    const float fz0 = dense_coord(lo.z, D.lo_z, inv_dcell), fz1 = dense_coord(hi.z, D.lo_z, inv_dcell);
+    const float nx = (float)D.nx, ny = (float)D.ny, nz = (float)D.nz;
     // written so that a NaN coordinate counts as outside
     B.outside = !(fx0 >= 0.0f && fx1 < nx && fy0 >= 0.0f && fy1 < ny && fz0 >= 0.0f && fz1 < nz);
-    B.empty = !(fx1 >= 0.0f && fx0 < nx && fy1 >= 0.0f && fy0 < ny && fz1 >= 0.0f && fz0 < nz) || G.n_dense == 0;
+    B.empty = !(fx1 >= 0.0f && fx0 < nx && fy1 >= 0.0f && fy0 < ny && fz1 >= 0.0f && fz0 < nz);
     B.x0 = (int)fminf(fmaxf(fx0, 0.0f), nx - 1.0f), B.x1 = (int)fminf(fmaxf(fx1, 0.0f), nx - 1.0f);
     B.y0 = (int)fminf(fmaxf(fy0, 0.0f), ny - 1.0f), B.y1 = (int)fminf(fmaxf(fy1, 0.0f), ny - 1.0f);
     B.z0 = (int)fminf(fmaxf(fz0, 0.0f), nz - 1.0f), B.z1 = (int)fminf(fmaxf(fz1, 0.0f), nz - 1.0f);
     return B;
 }
-// the records of row (y, z), cells x0..x1: one contiguous run
-__device__ __forceinline__ uint2 dense_run(const DevPhotonMap &G, int x0, int x1, int y, int z) {
-    const uint32_t row = ((uint32_t)z * G.ny + (uint32_t)y) * G.nx;
+// the grid a position is filed in (the first whose box holds it) and its cell there; false: an outlier
+RRT_HD bool dense_cell_of(const DevPhotonMap &G, float x, float y, float z, uint32_t &cell) {
+    for (uint32_t g = 0; g < G.n_grids; g++) {
+        const DenseGrid &D = G.grid[g];
+        const float fx = dense_coord(x, D.lo_x, G.inv_dcell), fy = dense_coord(y, D.lo_y, G.inv_dcell), fz = dense_coord(z, D.lo_z, G.inv_dcell);
+        if (fx >= 0.0f && fx < (float)D.nx && fy >= 0.0f && fy < (float)D.ny && fz >= 0.0f && fz < (float)D.nz) {
+            cell = D.cell_base + ((uint32_t)fz * D.ny + (uint32_t)fy) * D.nx + (uint32_t)fx;
+            return true;
+        }
+    }
+    return false;
+}
+// the records of row (y, z) of a grid, cells x0..x1: one contiguous run
+__device__ __forceinline__ uint2 dense_run(const DevPhotonMap &G, const DenseGrid &D, int x0, int x1, int y, int z) {
+    const uint32_t row = D.cell_base + ((uint32_t)z * D.ny + (uint32_t)y) * D.nx;
     const uint32_t first = G.dense_start[row + (uint32_t)x0], end = G.dense_start[row + (uint32_t)x1 + 1u];
     return make_uint2(first, end - first);
 }
@@ -172,15 +189,19 @@ __device__ __forceinline__ void visit_outlier_cells(const DevPhotonMap &G, f3 lo
         for (uint32_t cy = y0; cy <= y1; cy++)
             for (uint32_t cz = z0; cz <= z1; cz++) f(lookup_cell(G, cell_key(cx, cy, cz)));
 }
-// every run of records that may hold photons of the closed box [lo, hi]: dense rows in (z, y) order, then outlier cells
+// every run of records that may hold photons of the closed box [lo, hi]: per grid the rows in (z, y) order, then outlier cells
 template <class F>
 __device__ __forceinline__ void visit_runs(const DevPhotonMap &G, f3 lo, f3 hi, F &&f) {
     if (G.count == 0) return;
-    const DenseBox B = dense_box(G, lo, hi);
-    if (!B.empty)
-        for (int z = B.z0; z <= B.z1; z++)
-            for (int y = B.y0; y <= B.y1; y++) f(dense_run(G, B.x0, B.x1, y, z));
-    if (B.outside) visit_outlier_cells(G, lo, hi, f);
+    for (uint32_t g = 0; g < G.n_grids; g++) {
+        const DenseGrid &D = G.grid[g];
+        const DenseBox B = dense_box(D, G.inv_dcell, lo, hi);
+        if (!B.empty)
+            for (int z = B.z0; z <= B.z1; z++)
+                for (int y = B.y0; y <= B.y1; y++) f(dense_run(G, D, B.x0, B.x1, y, z));
+        if (!B.outside) return;  // the whole box lies in this grid's box: nothing of it can be filed further down
+    }
+    visit_outlier_cells(G, lo, hi, f);
 }
 
 // PhotonTree::get_within_distance (photon_tree.rs:15-35) + the accumulation of
@@ -206,17 +227,21 @@ __device__ __forceinline__ bool lookup_cells(const DevPhotonMap &G, f3 lo, f3 hi
 #pragma unroll
     for (uint32_t c = 0; c < 9; c++) C.rg[c] = make_uint2(0, 0);
     if (G.count == 0) return true;
-    const DenseBox B = dense_box(G, lo, hi);
-    if (B.outside && G.n_dense != G.count) return false;  // may hold outliers: the general walk
-    if (B.empty) return true;
-    if (B.y1 - B.y0 > 2 || B.z1 - B.z0 > 2) return false;  // rounding made it 4 cells along an axis
+    for (uint32_t g = 0; g < G.n_grids; g++) {
+        const DenseGrid &D = G.grid[g];
+        const DenseBox B = dense_box(D, G.inv_dcell, lo, hi);
+        if (B.empty) continue;           // nothing of the box in this grid: the next one
+        if (B.outside) return false;     // partly in this grid: the general walk
+        if (B.y1 - B.y0 > 2 || B.z1 - B.z0 > 2) return false;  // rounding made it 4 cells along an axis
 #pragma unroll
-    for (int c = 0; c < 9; c++) {
-        const int y = B.y0 + c % 3, z = B.z0 + c / 3;
-        if (y <= B.y1 && z <= B.z1) C.rg[c] = dense_run(G, B.x0, B.x1, y, z);
-        C.candidates += C.rg[c].y;
+        for (int c = 0; c < 9; c++) {
+            const int y = B.y0 + c % 3, z = B.z0 + c / 3;
+            if (y <= B.y1 && z <= B.z1) C.rg[c] = dense_run(G, D, B.x0, B.x1, y, z);
+            C.candidates += C.rg[c].y;
+        }
+        return true;
     }
-    return true;
+    return G.n_dense == G.count;  // outside every grid: only outliers can be there, if there are any
 }
 __device__ __forceinline__ void stream_cells(const DevPhotonMap &G, const CellSet &C, f3 lo, f3 hi, GatherSums &s) {
     s.ldir = mk3(0.0f, 0.0f, 0.0f);
@@ -350,15 +375,21 @@ __device__ __forceinline__ int average_photon_at(const DevPhotonMap maps[2], f3 
         return blend_estimates(reg, cau, incident, intensity) ? 1 : 0;
     }
     f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);  // photon_tree.rs:16-18
+    // Each map on its own: the common case is a box inside one dense grid (9 runs, known before a record is read); a box
+    // that straddles grid boxes or may hold outliers takes the general walk FOR THAT MAP only (the caustic map is small
+    // and most queries fall outside its grids: that must not push the regular map's lookup onto the slow path as well).
     CellSet c0, c1;
-    if (lookup_cells(maps[0], lo, hi, c0) && lookup_cells(maps[1], lo, hi, c1)) {
-        if (c0.candidates + c1.candidates > defer_above) return 2;
+    const bool fast0 = lookup_cells(maps[0], lo, hi, c0), fast1 = lookup_cells(maps[1], lo, hi, c1);
+    // the heavy-query decision from what is known without reading records (a function of the query and the maps alone)
+    if ((fast0 ? c0.candidates : 0u) + (fast1 ? c1.candidates : 0u) > defer_above) return 2;
+    if (fast0)
         stream_cells(maps[0], c0, lo, hi, reg);
-        stream_cells(maps[1], c1, lo, hi, cau);
-    } else {  // a box that leaves the dense region, or touches 4 cells along an axis (rounding): the general walk
+    else
         gather_box(maps[0], p, r, reg);
+    if (fast1)
+        stream_cells(maps[1], c1, lo, hi, cau);
+    else
         gather_box(maps[1], p, r, cau);
-    }
     gathered += reg.k + cau.k;
     candidates += reg.candidates + cau.candidates;
     return blend_estimates(reg, cau, incident, intensity) ? 1 : 0;

@@ -16,6 +16,13 @@ struct DevCamera {
 };
 
 // photon index in HBM (dev_photon.h)
+#define RRT_DENSE_GRIDS 4
+struct DenseGrid {
+    float lo_x, lo_y, lo_z;   // the grid covers [lo, lo + n * cell)
+    uint32_t nx, ny, nz;
+    uint32_t cell_base;       // index of its first cell in dense_start
+    uint32_t pad;
+};
 struct DevPhotonMap {
     const float4 *pos_cell;  // [n] position.xyz, w unused (cell-sorted: dense cells first, then the outliers' hash cells)
     const float4 *incident;  // [n] normalised-again incident.xyz (photon_scene.rs:405), w unused
@@ -25,11 +32,13 @@ struct DevPhotonMap {
     uint32_t table_mask;
     uint32_t count;
     float inv_cell;          // hash grid: 1 / (2 * half_width)
-    // dense grid over [dlo, dlo + n * cell): cell (x, y, z) holds records [dense_start[i], dense_start[i + 1]), i = (z * ny + y) * nx + x
-    const uint32_t *dense_start;  // [nx * ny * nz + 1]
-    uint32_t nx, ny, nz;
+    // Dense grids, cell edge = half_width, tried in order: a record lies in the first grid whose box holds it.  Cell
+    // (x, y, z) of grid g holds records [dense_start[i], dense_start[i + 1]), i = cell_base + (z * ny + y) * nx + x: one start
+    // table over all grids, records sorted by that index.
+    const uint32_t *dense_start;  // [cells of all grids + 1]
+    DenseGrid grid[RRT_DENSE_GRIDS];
+    uint32_t n_grids;
     uint32_t n_dense;        // records [0, n_dense) lie in dense cells, [n_dense, count) are outliers
-    float dlo_x, dlo_y, dlo_z;
     float inv_dcell;         // 1 / half_width
     const uint64_t *meta;    // [n] record keys (cell order): ties between equal squared distances (k-nearest estimator, queries)
 };

@@ -284,9 +284,9 @@ __global__ void k_cell_keys(const float4 *pos, uint32_t n, DevPhotonMap G, uint6
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = pos[i];
-    const float fx = dense_coord(p.x, G.dlo_x, G.inv_dcell), fy = dense_coord(p.y, G.dlo_y, G.inv_dcell), fz = dense_coord(p.z, G.dlo_z, G.inv_dcell);
-    if (fx >= 0.0f && fx < (float)G.nx && fy >= 0.0f && fy < (float)G.ny && fz >= 0.0f && fz < (float)G.nz)
-        keys[i] = ((uint64_t)(uint32_t)fz * G.ny + (uint32_t)fy) * G.nx + (uint32_t)fx;
+    uint32_t cell;
+    if (dense_cell_of(G, p.x, p.y, p.z, cell))
+        keys[i] = cell;
     else
         keys[i] = PH_OUTLIER_BIT | cell_key(cell_coord(p.x, G.inv_cell), cell_coord(p.y, G.inv_cell), cell_coord(p.z, G.inv_cell));
     idx[i] = i;
@@ -498,26 +498,17 @@ static int sort_by_meta(PhotonScratch &W, PhotonBuffers &b) {
     return RRT_OK;
 }
 
-// The dense region.  Photon maps have heavy tails: the reference's infinite planes catch photons (and, behind every
-// landing, shadow photons) thousands of units away, while the queries of a frame fall where the scene is.  The region
-// starts as the box of (all but the outermost 0.2 % per side of) a strided sample of the positions and is trimmed face by
-// face — always the face whose outer 20 % slab holds the fewest samples — until its grid fits the cell budget (4 cells per
-// record, between 2^20 and 2^24 cells): sparse tails go first, from whichever side they are on, the dense core stays.
+// The dense grids.  Photon maps have heavy tails: the reference's infinite planes catch photons (and, behind every
+// landing, shadow photons) thousands of units away, while the queries of a frame fall where the scene is; and they are
+// mostly surfaces, so one box over everything that matters would be nearly all empty cells.  From a strided sample of the
+// positions: a grid's box starts as the box of (all but the outermost 0.2 % per side of) the samples no earlier grid holds
+// and is trimmed face by face — always the face whose outer 20 % slab holds the fewest samples — until it fits the cell
+// budget (4 cells per record of the map, between 2^20 and 2^24 cells per grid): sparse tails and empty heights go first,
+// the dense part stays.  The first grid ends up around the middle of the scene, the next ones as thin slabs along the
+// floor and walls around it.  Grids are added until fewer than 3 % of the samples are left over (or RRT_DENSE_GRIDS).
 // Deterministic in the record set (the records are in canonical order here), and only performance depends on it:
-// records outside the region go to the hash grid.
-static int choose_dense_region(rrt_scene *s, const PhotonBuffers &b, uint32_t n, float cell, PhotonIndex &X) {
-    PhotonScratch &W = s->photon_scratch;
-    const uint32_t n_samples = std::min<uint32_t>(n, 2048), stride = std::max<uint32_t>(1, n / n_samples);
-    int rc = W.t.ensure(n_samples);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_sample_positions, grid_for(n_samples), dim3(256), 0, nullptr, b.pos.p, n, stride, n_samples, W.t.p);
-    std::vector<float4> host(n_samples);
-    RRT_HIP(hipMemcpy(host.data(), W.t.p, (size_t)n_samples * sizeof(float4), hipMemcpyDeviceToHost));
-    std::vector<std::array<float, 3>> pts;
-    pts.reserve(n_samples);
-    for (const float4 &p : host)
-        if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) pts.push_back({p.x, p.y, p.z});
-    if (pts.empty()) pts.push_back({0.0f, 0.0f, 0.0f});
+// records outside every box go to the hash grid.
+static void choose_dense_box(const std::vector<std::array<float, 3>> &pts, double budget, float cell, DenseGrid &D) {
     double lo[3], hi[3];
     {
         std::vector<float> v(pts.size());
@@ -529,7 +520,6 @@ static int choose_dense_region(rrt_scene *s, const PhotonBuffers &b, uint32_t n,
             hi[a] = v[(size_t)(0.998 * (double)m)];
         }
     }
-    const double budget = (double)std::min<uint64_t>(std::max<uint64_t>(4ull * n, 1ull << 20), 1ull << 24);
     auto cells_of = [&](int a) { return std::max(1.0, std::ceil((hi[a] - lo[a]) / (double)cell) + 4.0); };
     for (int it = 0; it < 400 && cells_of(0) * cells_of(1) * cells_of(2) > budget; it++) {
         double cut[6];  // new position of face 2a (low) / 2a + 1 (high)
@@ -565,8 +555,44 @@ static int choose_dense_region(rrt_scene *s, const PhotonBuffers &b, uint32_t n,
         int a = dims[0] >= dims[1] && dims[0] >= dims[2] ? 0 : (dims[1] >= dims[2] ? 1 : 2);
         dims[a] = std::max(1.0, std::floor(dims[a] / 2.0));
     }
-    X.dlo[0] = (float)lo[0], X.dlo[1] = (float)lo[1], X.dlo[2] = (float)lo[2];
-    X.nx = (uint32_t)dims[0], X.ny = (uint32_t)dims[1], X.nz = (uint32_t)dims[2];
+    D.lo_x = (float)lo[0], D.lo_y = (float)lo[1], D.lo_z = (float)lo[2];
+    D.nx = (uint32_t)dims[0], D.ny = (uint32_t)dims[1], D.nz = (uint32_t)dims[2];
+}
+static int choose_dense_grids(rrt_scene *s, const PhotonBuffers &b, uint32_t n, float cell, PhotonIndex &X) {
+    PhotonScratch &W = s->photon_scratch;
+    const uint32_t n_samples = std::min<uint32_t>(n, 2048), stride = std::max<uint32_t>(1, n / n_samples);
+    int rc = W.t.ensure(n_samples);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sample_positions, grid_for(n_samples), dim3(256), 0, nullptr, b.pos.p, n, stride, n_samples, W.t.p);
+    std::vector<float4> host(n_samples);
+    RRT_HIP(hipMemcpy(host.data(), W.t.p, (size_t)n_samples * sizeof(float4), hipMemcpyDeviceToHost));
+    std::vector<std::array<float, 3>> pts;
+    pts.reserve(n_samples);
+    for (const float4 &p : host)
+        if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) pts.push_back({p.x, p.y, p.z});
+    if (pts.empty()) pts.push_back({0.0f, 0.0f, 0.0f});
+    const size_t all = pts.size();
+    const double budget = (double)std::min<uint64_t>(std::max<uint64_t>(4ull * n, 1ull << 20), 1ull << 24);
+    X.n_grids = 0;
+    X.dense_cells = 0;
+    const float inv = 1.0f / cell;
+    static const char *max_env = getenv("RRT_DENSE_GRIDS_MAX");  // experiments: fewer grids
+    const uint32_t max_grids = max_env ? std::min<uint32_t>(std::max(1, atoi(max_env)), RRT_DENSE_GRIDS) : 1u;
+    while (X.n_grids < max_grids && !pts.empty() && (X.n_grids == 0 || pts.size() * 100 >= all * 3)) {
+        DenseGrid &D = X.grids[X.n_grids];
+        choose_dense_box(pts, budget, cell, D);
+        D.cell_base = X.dense_cells;
+        D.pad = 0;
+        X.dense_cells += D.nx * D.ny * D.nz;
+        X.n_grids++;
+        std::vector<std::array<float, 3>> rest;  // the samples this grid does not hold, filed like the records will be
+        for (const auto &p : pts) {
+            const float fx = dense_coord(p[0], D.lo_x, inv), fy = dense_coord(p[1], D.lo_y, inv), fz = dense_coord(p[2], D.lo_z, inv);
+            if (!(fx >= 0.0f && fx < (float)D.nx && fy >= 0.0f && fy < (float)D.ny && fz >= 0.0f && fz < (float)D.nz)) rest.push_back(p);
+        }
+        if (rest.size() == pts.size()) break;  // a box that holds none of its samples: stop rather than repeat it
+        pts.swap(rest);
+    }
     return RRT_OK;
 }
 
@@ -581,16 +607,16 @@ static int build_index(rrt_scene *s, int which) {
     X.table_size = 0;
     X.crowding = 0.0;
     X.n_dense = 0;
-    X.nx = X.ny = X.nz = 1;
-    X.dlo[0] = X.dlo[1] = X.dlo[2] = 0.0f;
+    X.n_grids = 0;
+    X.dense_cells = 0;
     s->map_view[which] = X.view();
     if (n == 0) return RRT_OK;
     if (!(cell > 0.0f) || !std::isfinite(X.inv_dcell)) return fail(RRT_ERR_INVALID, "gather_half_width must be positive");
     int rc;
     PhotonScratch &W = s->photon_scratch;
     if ((rc = sort_by_meta(W, b))) return rc;  // canonical order first; the cell sort below is stable
-    if ((rc = choose_dense_region(s, b, n, cell, X))) return rc;
-    const uint32_t cells = X.nx * X.ny * X.nz;
+    if ((rc = choose_dense_grids(s, b, n, cell, X))) return rc;
+    const uint32_t cells = X.dense_cells;
     DBuf<uint64_t> &keys = W.keys, &keys2 = W.keys2;
     DBuf<uint32_t> &idx = W.idx, &idx2 = W.idx2, &ncell = W.ncell;
     if ((rc = keys.ensure(std::max<size_t>(n, 512))) || (rc = keys2.ensure(n)) || (rc = idx.ensure(n)) || (rc = idx2.ensure(n)) ||
@@ -640,9 +666,13 @@ static int build_index(rrt_scene *s, int which) {
         for (int k = 0; k < 64; k++) sum += part[k * 8];
         X.crowding = (double)sum / (double)n;
     }
-    if (getenv("RRT_INDEX_INFO"))
-        fprintf(stderr, "[index %d] %u records: %u in a %u x %u x %u dense grid (cell %.3g, from %.3f %.3f %.3f), %u outliers in %u hash cells; crowding %.1f\n",
-                which, n, n_dense, X.nx, X.ny, X.nz, cell, X.dlo[0], X.dlo[1], X.dlo[2], n_out, out_cells, X.crowding);
+    if (getenv("RRT_INDEX_INFO")) {
+        fprintf(stderr, "[index %d] %u records: %u in %u dense grids (cell %.3g, %u cells), %u outliers in %u hash cells; crowding %.1f\n", which, n,
+                n_dense, X.n_grids, cell, cells, n_out, out_cells, X.crowding);
+        for (uint32_t g = 0; g < X.n_grids; g++)
+            fprintf(stderr, "[index %d]   grid %u: %u x %u x %u from %.3f %.3f %.3f\n", which, g, X.grids[g].nx, X.grids[g].ny, X.grids[g].nz,
+                    X.grids[g].lo_x, X.grids[g].lo_y, X.grids[g].lo_z);
+    }
     RRT_HIP(hipDeviceSynchronize());
     s->map_view[which] = X.view();
     return RRT_OK;

@@ -67,9 +67,9 @@ DevPhotonMap PhotonIndex::view() const {
     m.count = (uint32_t)count;
     m.inv_cell = inv_cell;
     m.dense_start = dense_start.p;
-    m.nx = nx, m.ny = ny, m.nz = nz;
+    for (int g = 0; g < RRT_DENSE_GRIDS; g++) m.grid[g] = grids[g];
+    m.n_grids = n_grids;
     m.n_dense = n_dense;
-    m.dlo_x = dlo[0], m.dlo_y = dlo[1], m.dlo_z = dlo[2];
     m.inv_dcell = inv_dcell;
     m.meta = meta.p;
     return m;
@@ -795,6 +795,19 @@ static int run_round_by_level(FrameRun &R, std::vector<ChunkPlan> &plan) {
             float ms = 0.0f;
             RRT_HIP(hipEventElapsedTime(&ms, L.ev_trace0, L.ev_trace1));
             R.ms_trace += ms;
+            static const bool level_stats = getenv("RRT_LEVEL_STATS") != nullptr;  // debugging aid (with RRT_LEVEL_SYNC=1)
+            if (level_stats) {
+                static unsigned long long seen[ST_COUNT];
+                unsigned long long all[RRT_STAT_WORDS], now[ST_COUNT] = {0};
+                RRT_HIP(hipMemcpy(all, s->stats_dev.p, sizeof(all), hipMemcpyDeviceToHost));
+                for (int q = 0; q < ST_COUNT; q++)
+                    for (int c = 0; c < RRT_STAT_COPIES; c++) now[q] += all[c * RRT_STAT_STRIDE + q];
+                if (k == 0) memset(seen, 0, sizeof(seen));
+                fprintf(stderr, "[level %u] %u rays, %.3f ms: box tests %llu, shadow rays %llu, gather queries %llu, candidates %llu, gathered %llu\n", k,
+                        counts[k], ms, now[ST_NODES] - seen[ST_NODES], now[ST_SHADOW] - seen[ST_SHADOW], now[ST_QUERIES] - seen[ST_QUERIES],
+                        now[ST_CANDIDATES] - seen[ST_CANDIDATES], now[ST_GATHERED] - seen[ST_GATHERED]);
+                memcpy(seen, now, sizeof(seen));
+            }
             counts[k + 1] = next_n;
             R.secondary += next_n;
             if (next_n == 0) break;

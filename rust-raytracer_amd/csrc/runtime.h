@@ -94,8 +94,8 @@ struct PhotonIndex {
     uint64_t count = 0;
     float inv_cell = 0.0f;   // hash grid, cell edge 2r
     float inv_dcell = 0.0f;  // dense grid, cell edge r
-    float dlo[3] = {0.0f, 0.0f, 0.0f};
-    uint32_t nx = 1, ny = 1, nz = 1;
+    DenseGrid grids[RRT_DENSE_GRIDS] = {};  // dense grids in the order records are tried against them
+    uint32_t n_grids = 0, dense_cells = 0;
     uint32_t n_dense = 0;
     double crowding = 0.0;  // sum over cells of count^2 / records: the occupancy of the cell a random photon lies in
     DevPhotonMap view() const;
