@@ -346,3 +346,16 @@ def test_rust_bindings_cover_the_header(repo):
     # constants that size arrays
     assert "RRT_MAX_COMPOUND_PARTS: usize = 4" in rs and "#define RRT_MAX_COMPOUND_PARTS 4" in hdr
     assert "RRT_NOALLOC_MAX_RAYS: usize = 65536" in rs and "RRT_GATHER_K_MAX: u32 = 4096" in rs
+
+
+def test_device_trace_code_in_the_wave_emulator(repo):
+    """tools/cpu_emu: the device's trace code (dev_trace.h: record loop, CSG hit lists, the four-wide BVH walk with both LDS
+    stack layouts) compiled for the CPU and run in 64-lane lockstep waves under ASan / UBSan with an ownership check on every
+    LDS access, against the oracle: generated scenes and a 25 k-triangle mesh (deep tree, threaded SAH build, collapse)."""
+    import subprocess
+    import sys
+
+    subprocess.check_call(["bash", os.path.join(repo, "tools/cpu_emu/build.sh")])
+    out = subprocess.run([sys.executable, os.path.join(repo, "tools/cpu_emu/check_random_scenes.py"), "0", "6"], capture_output=True, text=True,
+                         env=dict(os.environ, EMU_TEAPOTS="1"))
+    assert out.returncode == 0 and "ALL OK" in out.stdout and "teapots: mesh hits" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

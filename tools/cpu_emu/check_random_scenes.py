@@ -1,6 +1,6 @@
 """CPU pre-flight for kernel changes: random scenes (tests/scene_kit.random_scene) through the DEVICE trace code in the
 wave emulator (tools/cpu_emu/emu, ASan + LDS ownership check) against the oracle.  No GPU needed.
-   usage: python tools/cpu_emu/check_random_scenes.py [first_seed [count]]"""
+   usage: python tools/cpu_emu/check_random_scenes.py [first_seed [count]]      (EMU_TEAPOTS=1: also a 25 k-triangle mesh)"""
 import os, subprocess, sys, tempfile
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +12,41 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 emu = os.path.join(REPO, "tools/cpu_emu/emu")
 tmp = tempfile.mkdtemp()
 bad = 0
-for seed in range(first, first + count):
+def teapots(scene):
+    """2 x 2 teapots (25 280 triangles: a tree deep enough for the four-wide collapse and the threaded SAH build to matter),
+    smooth, plus a floor; rays come from around the grid."""
+    import bench_extra
+    pos, nrm = bench_extra.teapot_grid(2, 2)
+    m = kit.monochrome(scene, (0.7, 0.5, 0.3))
+    scene.add_object(kit.mesh(scene, pos, nrm, m, True))
+    scene.add_object(kit.plane(scene, (0.0, -0.5, 0.0), (0.0, 0.0, 1.0), (0.0, 1.0, 0.0), m))
+    return scene
+
+seeds = list(range(first, first + count))
+if os.environ.get("EMU_TEAPOTS"):
+    seeds.append("teapots")
+for seed in seeds:
     os.environ["RRT_DUMP_SCENE"] = os.path.join(tmp, "scene.bin")
+    if seed == "teapots":
+        gpu = teapots(rrt.Scene())
+        try:
+            gpu.pre_render(1)
+        except rrt.RrtError as e:
+            assert e.code == abi.ERR_DEVICE, e
+        cpu = teapots(ob.OracleScene())
+        o, d = kit.coherent_rays(3000, 5, origin_scale=60.0, towards=(0.0, 5.0, 0.0), spread=25.0)
+        np.concatenate([o, d], axis=1).astype(np.float32).tofile(os.path.join(tmp, "rays.f32"))
+        r = subprocess.run([emu, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "rays.f32"), os.path.join(tmp, "out.bin")], capture_output=True, text=True,
+                           env=dict(os.environ, EMU_SHADOW_LIMIT="40"))
+        if r.returncode:
+            print("teapots EMULATOR FAILED\n", r.stderr[-2000:]); bad += 1; continue
+        out = np.fromfile(os.path.join(tmp, "out.bin"), np.uint32).reshape(-1, 4)
+        c = cpu.trace(o, d)
+        sh = cpu.shadowtrace(o, d, np.full(o.shape[0], 40.0, np.float32))
+        mism = [(out[:, 0] != c["object_id"]).sum(), (out[:, 1] != c["distance"].view(np.uint32)).sum(), (out[:, 2] != c["prim_id"]).sum(), (out[:, 3] != sh).sum()]
+        print("teapots: mesh hits %.2f mismatches (id, t, prim, shadow) %s" % ((c["object_id"] == 0).mean(), mism))
+        bad += any(mism)
+        continue
     gpu = kit.random_scene(rrt.Scene(), seed)
     try:
         gpu.pre_render(1)   # dumps the arrays, then fails for want of a GPU (or succeeds on a GPU box)
