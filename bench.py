@@ -10,8 +10,9 @@ N ranks render ONE frame together (north_star: "image tiles shard over GPUs"): i
 of 8 (rrt_render_interleaved_device: contiguous bands would leave the ranks with the sky idle), every rank renders its
 share into one packed buffer, and ONE RCCL gather per frame brings the shares to rank 0, which puts the rows back in
 image order.  Total work is fixed as N grows: "scaling": "strong".  The gather of frame f overlaps the rendering of
-frame f + 1 (two buffers); `collective_ms` is the time rank 0 spends waiting for gathers per step and
-`collective_gb_per_s` the bytes it received per step over that time.  At N = 1 there is no collective and the frame is
+frame f + 1 (two buffers); `collective_ms` is that gather timed on its own (after the timed region, five repeats),
+`collective_gb_per_s` the bytes rank 0 receives over that time, `collective_exposed_ms` what of it the timed region had to
+wait for per step.  At N = 1 there is no collective and the frame is
 rendered straight into the frame buffers: the N = 1 value IS the single-GPU number.
 
 The same JSON line carries
@@ -215,6 +216,17 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     repeated = scene.stats()["frames_repeated"] - repeated_before
+    # the frame gather by itself (in the timed region it hides behind the next frame's kernels; only what is left of it
+    # shows up there as waiting time)
+    gather_alone_ms = 0.0
+    if world > 1:
+        fg.gather_only(0)
+        sync()
+        t = time.perf_counter()
+        for _ in range(5):
+            fg.gather_only(0)
+        sync()
+        gather_alone_ms = (time.perf_counter() - t) / 5 * 1e3
     rays, kernel_ms, flops, wait_ms, st = acc["rays"], acc["kernel_ms"], acc["flops"], acc["wait_ms"], acc["st"]
     if dist is not None:
         t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=reduce_device)
@@ -262,8 +274,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "collective_ms": wait_ms / args.steps if world > 1 else 0.0,
-            "collective_gb_per_s": (gather_bytes * args.steps / (wait_ms * 1e-3) / 1e9) if world > 1 and wait_ms > 0 else None,
+            # the gather of one frame to rank 0 timed on its own, and what of it the timed region had to wait for per step
+            "collective_ms": gather_alone_ms if world > 1 else 0.0,
+            "collective_gb_per_s": (gather_bytes / (gather_alone_ms * 1e-3) / 1e9) if world > 1 and gather_alone_ms > 0 else None,
+            "collective_exposed_ms": wait_ms / args.steps if world > 1 else 0.0,
             "config": {
                 "workload": "BASELINE configs[3]: %d-triangle mesh (13x13 grid of assets/models/teapot.obj) + floor, 1 point light, 3840x2160, "
                             "%s; one frame per step, frames one at a time" % (ntri, args.variant),

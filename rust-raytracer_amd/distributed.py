@@ -266,6 +266,15 @@ class FrameGather:
                 src = self.stage[k]
             self.pending[k] = self.dist.gather(src, outs, dst=0, async_op=True)
 
+    def gather_only(self, k):
+        """The collective of buffer k by itself, complete on return (for timing it; no assembly)."""
+        self.start_gather(k)
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+            self.pending[k] = None
+        if str(self.device).startswith("cuda"):
+            torch.cuda.synchronize()
+
     def finish(self, k):
         """Waits for buffer k's collective; rank 0 then assembles the frame (rows back in image order)."""
         if self.pending[k] is not None:
