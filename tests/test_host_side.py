@@ -359,3 +359,34 @@ def test_device_trace_code_in_the_wave_emulator(repo):
     out = subprocess.run([sys.executable, os.path.join(repo, "tools/cpu_emu/check_random_scenes.py"), "0", "6"], capture_output=True, text=True,
                          env=dict(os.environ, EMU_TEAPOTS="1"))
     assert out.returncode == 0 and "ALL OK" in out.stdout and "teapots: mesh hits" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_scene_files_through_an_independent_reader(repo, name):
+    """Common-mode check of the scene plumbing.  The oracle is normally fed by the product's C++ parser, OBJ and PPM readers;
+    here every scene file is ALSO read by tests/independent_scene.py (a Python restatement of scene_file.rs with its own
+    grammar, builders, OBJ and P6 readers) into a second oracle scene.  Both must look the same to rays, bit for bit: hits
+    (object, leaf / triangle, distance, position, normal, uv) on camera and random rays, shadow rays, and — materials,
+    textures and lights — the raytraced colours."""
+    import independent_scene as ind
+
+    path = os.path.join(repo, "assets/scenes", name + ".txt")
+    a, cam_a = ob.OracleScene.load(path, mode_override=abi.MODE_SCENE)
+    b, cam_b, mode = ind.load(open(path).read(), lambda m: ob.OracleScene(abi.MODE_SCENE), ob.make_camera, repo)
+    assert mode == (abi.MODE_PHOTON if name == "scene2" else abi.MODE_SCENE)
+    assert bytes(cam_a) == bytes(cam_b)
+    assert a.object_count() == b.object_count() == EXPECT_OBJECTS[name]
+    rays = [ob.camera_ray(cam_a, x, y) for y in range(8, cam_a.height, cam_a.height // 20) for x in range(8, cam_a.width, cam_a.width // 20)]
+    o = np.array([r[0] for r in rays], np.float32)
+    d = np.array([r[1] for r in rays], np.float32)
+    o2, d2 = kit.random_rays(300, 3, origin_scale=6.0, towards=(0.0, 1.0, 6.0), spread=5.0)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    ra, rb = a.trace(o, d), b.trace(o, d)
+    assert (ra["object_id"] != abi.MISS).mean() > 0.15
+    for k in ra:
+        assert np.array_equal(ra[k].view(np.uint32), rb[k].view(np.uint32)), k
+    lim = np.full(o.shape[0], 3.0, np.float32)
+    assert np.array_equal(a.shadowtrace(o, d, lim), b.shadowtrace(o, d, lim))
+    ca, cb = a.raytrace(o, d), b.raytrace(o, d)
+    for x, y in zip(ca, cb):
+        assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32))
