@@ -302,7 +302,7 @@ int rrt_raytrace(rrt_scene *s, const float *origins, const float *directions, si
                  float *depth, uint32_t *object_id);
 /* replaces: Environment::trace (environment.rs:55-74), batched, for parity tests: the first
  * entering hit with distance >= 0.  Outputs (each may be NULL): object_id [n] (0xFFFFFFFF =
- * miss), prim_id [n] (triangle index for meshes, leaf index in CSG post-order, else 0),
+ * miss), prim_id [n] (triangle index for meshes, leaf index in CSG post-order (mesh leaves too), else 0),
  * distance [n], position [n][3], normal [n][3], uv [n][2] (NaN when tex_coords is None).    */
 int rrt_trace(rrt_scene *s, const float *origins, const float *directions, size_t n,
               uint32_t *object_id, uint32_t *prim_id, float *distance, float *position,

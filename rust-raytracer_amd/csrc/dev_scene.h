@@ -130,7 +130,7 @@ struct DevScene {
     uint32_t n_prog;
     uint32_t n_objects;
     uint32_t n_lights;
-    uint32_t has_csg;
+    uint32_t has_csg;   // bit 0: some object is a CSG tree; bit 1: some CSG tree has a mesh leaf (the BVH stack then lies behind the hit lists in LDS)
     uint32_t has_bounds;
     uint32_t n_plane_cold, n_meshes, n_materials;  // array sizes, for the device-side index guards
     const PlaneCold *plane_cold;
@@ -139,6 +139,10 @@ struct DevScene {
     const uint32_t *tri_index; // BVH order -> original triangle index
     const float *tri_normals;  // [orig tri][3][3], only for smooth meshes
     const BvhNodeQ *nodes;
+    // Meshes that are CSG leaves only: [2 m], [2 m + 1] = first, count of mesh m's entries behind the 2 * n_meshes header
+    // words; an entry is the BVH-order slot of a triangle whose same-side test (triangle_object.rs:137-147) passes for
+    // Vertex::zero(), the position of the plane's Hit::infinity (hit.rs:37-52): see leaf_list in dev_trace.h
+    const uint32_t *mesh_inf;
     const DevMaterial *materials;
     const DevTexture *textures;
     const uchar4 *texels8;

@@ -26,8 +26,8 @@ __device__ __forceinline__ uint32_t mk_meta(bool entering, uint32_t instr, uint3
     return (entering ? META_ENTER : 0u) | (instr << 8) | sub;
 }
 
-// Per-block LDS views.  lists: [slot][entry][thread] of 8-byte entries; the BVH stack aliases the lists (meshes
-// cannot be CSG leaves, so a lane never uses both at once) and therefore MUST stay inside the lane's own 8-byte
+// Per-block LDS views.  lists: [slot][entry][thread] of 8-byte entries; the BVH stack aliases the lists (a lane never
+// uses both at once; scenes with a mesh leaf inside a CSG tree put it behind them: stack_base) and therefore MUST stay inside the lane's own 8-byte
 // column: the other waves of the block are at other records, and a stack laid out as [entry][thread] of 4-byte words
 // would put lane t's words into the list columns of lanes t/2 of another wave.  Two stack words per column element.
 // tools/cpu_emu defines this to assert that an access stays inside the block's LDS allocation and inside the
@@ -42,6 +42,8 @@ struct Lds {
     float2 *le;  // hit-list entries: (distance, meta word) as one 8-byte element -> ds_read_b64 / ds_write_b64
     int *stack;
     uint32_t nthreads, tid;
+    uint32_t stack_base = 0;  // 8-byte elements in front of the BVH stack: 0 (the stack aliases the hit lists: a lane never
+                              // needs both) unless a CSG tree has a mesh leaf, which is walked while hit lists are live
     __device__ __forceinline__ void get(uint32_t slot, uint32_t e, float &t, uint32_t &m) const {
         RRT_LDS_CHECK(*this, (slot * RRT_LIST_CAP + e) * nthreads + tid);
         float2 v = le[(slot * RRT_LIST_CAP + e) * nthreads + tid];
@@ -53,8 +55,8 @@ struct Lds {
         le[(slot * RRT_LIST_CAP + e) * nthreads + tid] = make_float2(t, __uint_as_float(m));
     }
     __device__ __forceinline__ int &st(uint32_t e) {
-        RRT_LDS_CHECK(*this, (e >> 1) * nthreads + tid);
-        return stack[(((e >> 1) * nthreads + tid) << 1) + (e & 1u)];
+        RRT_LDS_CHECK(*this, (stack_base + (e >> 1)) * nthreads + tid);
+        return stack[(((stack_base + (e >> 1)) * nthreads + tid) << 1) + (e & 1u)];
     }
     // Scenes without CSG keep nothing but traversal stacks in LDS, so the stack can be plain 4-byte words [word][lane]:
     // the next word is one constant stride away (one add per push or pop instead of the column arithmetic above).
@@ -448,8 +450,42 @@ __device__ __forceinline__ float4 rec4(const ProgRec &r) { return make_float4(r.
 
 // Leaf of a CSG program: write the primitive's hit list into LDS slot `slot`, return its length.
 // `k` = index of the record in the program (kept in the meta word so the winner can be re-evaluated).
-__device__ __forceinline__ uint32_t leaf_list(const ProgRec &r, uint32_t k, f3 o, f3 d, Lds &lds, uint32_t slot) {
+// A mesh leaf (csg_object.rs:25-36 takes any Box<dyn Object>): PolyMesh::intersect returns at most ONE hit, the nearest of
+// either facing with d >= 0 (polymesh_object.rs:216-242).  Its triangle does not fit the meta word; object_step looks it
+// up again for the winner.
+template <bool WITH_MESH>
+__device__ __forceinline__ uint32_t leaf_list(const DevScene &S, const ProgRec &r, uint32_t k, f3 o, f3 d, Lds &lds, uint32_t slot, Counters &cnt) {
     switch (r.op & 0xFFu) {
+        case OP_MESH: {
+            if (!WITH_MESH || r.aux >= S.n_meshes) return 0;
+            float t;
+            uint32_t tri;
+            bool ent;
+            const MeshInfo &M = S.meshes[r.aux];
+            if (mesh_closest<false>(S, M, o, d, RRT_INF, lds, cnt, t, tri, ent)) {
+                lds.put(slot, 0, t, mk_meta(ent, k, 0));
+                return 1;
+            }
+            // No finite hit.  A triangle's plane still reports Hit::infinity (position Vertex::zero()) as its exit when the
+            // ray runs against the normal or lies inside the half-space (plane_object.rs:60-67, 90-111); the triangle lets
+            // it pass when the world origin is inside its prism (mesh_inf lists those), and PolyMesh::intersect, having
+            // nothing nearer, returns it: an exit at +inf.
+            const uint32_t first = S.mesh_inf[2 * r.aux], n = S.mesh_inf[2 * r.aux + 1];
+            const uint32_t *slots = S.mesh_inf + 2 * S.n_meshes + first;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t ts = slots[j];
+                if (ts >= M.tri_count) break;  // index guard
+                const TriHot T = S.tris[M.tri_first + ts];
+                const f3 nrm = mk3(T.a_nx.w, T.b_ny.w, T.c_nz.w);
+                const float U = dot3(nrm, o) + T.d_pad.x, V = dot3(nrm, d);
+                const bool exits_at_inf = V == 0.0f ? U >= 0.0f : !(V > 0.0f);
+                if (exits_at_inf) {
+                    lds.put(slot, 0, RRT_INF, mk_meta(false, k, 0));
+                    return 1;
+                }
+            }
+            return 0;
+        }
         case OP_PLANE: {
             float t0, t1;
             bool e0, e1;
@@ -498,12 +534,13 @@ struct CsgState {
     uint32_t stack_slots = 0, sp = 0;  // slot ids of the live lists, 4 bits each
     uint32_t free_mask = 0xFFu;        // free LDS slots
     uint32_t len_l = 0;                // per-lane lengths of the live lists, 4 bits each by stack position
-    __device__ __forceinline__ void step(const ProgRec &r, uint32_t k, f3 o, f3 d, Lds &lds, Counters &cnt) {
+    template <bool WITH_MESH = true>
+    __device__ __forceinline__ void step(const DevScene &S, const ProgRec &r, uint32_t k, f3 o, f3 d, Lds &lds, Counters &cnt) {
         uint32_t op = r.op & 0xFFu;
         if (op < OP_CSG_UNION) {
             uint32_t slot = __builtin_ctz(free_mask);
             free_mask &= ~(1u << slot);
-            uint32_t n = leaf_list(r, k, o, d, lds, slot);
+            uint32_t n = leaf_list<WITH_MESH>(S, r, k, o, d, lds, slot, cnt);
             stack_slots = (stack_slots & ~(15u << (sp * 4))) | (slot << (sp * 4));
             len_l = (len_l & ~(15u << (sp * 4))) | (n << (sp * 4));
             sp++;
@@ -678,9 +715,17 @@ __device__ __forceinline__ bool object_step(const DevScene &S, uint32_t k, const
         return t_out < RRT_F32_MAX;  // select_first_hit starts from f32::MAX with a strict `<`
     }
     if (r.op & PF_FIRST) csg.reset();
-    csg.step(r, k, o, d, lds, cnt);
+    csg.template step<(FEAT & FEAT_MESH) != 0>(S, r, k, o, d, lds, cnt);
     if (!(r.op & PF_LAST)) return false;
-    return csg_first_hit(lds, csg.out_slot(), csg.out_len(), t_out, k_out, sub_out);
+    if (!csg_first_hit(lds, csg.out_slot(), csg.out_len(), t_out, k_out, sub_out)) return false;
+    if ((FEAT & FEAT_MESH) && (S.has_csg & 2u) && k_out < S.n_prog && (S.prog[k_out].op & 0xFFu) == OP_MESH) {
+        // the winner is a mesh leaf: which triangle it was (the hit lists are done with, the walk may use the LDS again)
+        const ProgRec &leaf = S.prog[k_out];
+        float t;
+        bool ent;
+        if (leaf.aux >= S.n_meshes || !mesh_closest<false>(S, S.meshes[leaf.aux], o, d, RRT_INF, lds, cnt, t, sub_out, ent)) return false;
+    }
+    return true;
 }
 
 template <int FEAT = FEAT_ALL>

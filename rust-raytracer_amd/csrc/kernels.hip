@@ -23,9 +23,10 @@ namespace rrt {
 
 extern __shared__ float4 g_smem[];
 
-__device__ __forceinline__ Lds make_lds(uint32_t lds_slots, uint32_t nthreads = RRT_BLOCK) {
+__device__ __forceinline__ Lds make_lds(const DevScene &S, uint32_t lds_slots, uint32_t nthreads = RRT_BLOCK) {
     Lds l;
     l.nthreads = nthreads;
+    l.stack_base = (S.has_csg & 2u) ? lds_slots * RRT_LIST_CAP : 0u;
     l.tid = threadIdx.x;
     l.le = reinterpret_cast<float2 *>(g_smem);
     l.stack = reinterpret_cast<int *>(g_smem);
@@ -143,7 +144,7 @@ __device__ __forceinline__ f3 scene_node_total(f3 once, uint32_t flags, float wr
 template <int MODE, int FEAT, int BLOCK, bool FUSE>
 __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
     const DevScene &S = A.S;
-    Lds lds = make_lds(A.lds_slots, BLOCK);
+    Lds lds = make_lds(A.S, A.lds_slots, BLOCK);
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t count = A.count_ptr ? min(*A.count_ptr, A.count) : A.count;
     bool active = i < count;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
 #define RRT_BATCH_WAVES 1
 #endif
 __global__ __launch_bounds__(RRT_BLOCK, RRT_BATCH_WAVES) void k_batch_trace(BatchTraceArgs A) {
-    Lds lds = make_lds(A.lds_slots);
+    Lds lds = make_lds(A.S, A.lds_slots);
     uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
     Counters cnt = {0, 0, 0, 0};
     if (i < A.n) {
@@ -486,16 +487,16 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_BATCH_WAVES) void k_batch_trace(Batc
         if (ok) {
             const ProgRec &in = A.S.prog[tr.instr];
             uint32_t op = in.op & 0xFFu;
-            if (op == OP_MESH) {
-                const MeshInfo &M = A.S.meshes[in.aux];
-                prim = A.S.tri_index[M.tri_first + tr.sub];
-            } else if (in.op & PF_CSG) {  // leaf number in post-order
+            if (in.op & PF_CSG) {  // leaf number in post-order (a mesh leaf too: the leaf, not its triangle)
                 uint32_t leaf = 0;
                 for (uint32_t k = tr.instr; k > 0 && !(A.S.prog[k].op & PF_FIRST);) {
                     k--;
                     if ((A.S.prog[k].op & 0xFFu) < OP_CSG_UNION) leaf++;
                 }
                 prim = leaf;
+            } else if (op == OP_MESH) {
+                const MeshInfo &M = A.S.meshes[in.aux];
+                prim = A.S.tri_index[M.tri_first + tr.sub];
             } else if (op == OP_CUBOID) {
                 prim = tr.sub;
             }
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_BATCH_WAVES) void k_batch_trace(Batc
 }
 
 __global__ __launch_bounds__(RRT_BLOCK, RRT_BATCH_WAVES) void k_batch_shadow(BatchTraceArgs A) {
-    Lds lds = make_lds(A.lds_slots);
+    Lds lds = make_lds(A.S, A.lds_slots);
     uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
     Counters cnt = {0, 0, 0, 0};
     if (i < A.n) {

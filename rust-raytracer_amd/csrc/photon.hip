@@ -93,6 +93,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
     lds.tid = threadIdx.x;
     lds.le = reinterpret_cast<float2 *>(g_smem_ph);
     lds.stack = reinterpret_cast<int *>(g_smem_ph);
+    lds.stack_base = (S.has_csg & 2u) ? A.lds_slots * RRT_LIST_CAP : 0u;  // see make_lds (kernels.hip)
     uint32_t gid = blockIdx.x * RRT_BLOCK + threadIdx.x;
     bool alive = gid < A.count;
     Counters cnt = {0, 0, 0, 0};
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
                     if (have) sub++;
                 } else {
                     if (rec.op & PF_FIRST) csg.reset();
-                    if (alive) csg.step(rec, k, so, sd, lds, cnt);
+                    if (alive) csg.step(S, rec, k, so, sd, lds, cnt);
                     if (!(rec.op & PF_LAST)) continue;
                     uint32_t slot = csg.out_slot(), n = alive ? csg.out_len() : 0;
                     for (uint32_t e = 0; e < RRT_LIST_CAP; e++) {

@@ -86,6 +86,8 @@ struct Flat {
     std::vector<uint32_t> tri_index;
     std::vector<float> tri_normals;
     std::vector<BvhNodeQ> nodes;
+    std::vector<std::vector<uint32_t>> mesh_inf;  // per mesh: triangle slots whose prism holds the world origin (CSG leaves only)
+    uint32_t csg_nesting = 0;                     // > 0 while emit is inside a CSG tree
     uint32_t bvh_depth = 0;
     uint64_t flops = 0;
     uint32_t bvh_builder = RRT_BVH_HOST_SAH;
@@ -286,6 +288,21 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
                 F.tris.push_back(t);
                 F.tri_index.push_back(order[k]);
             }
+            F.mesh_inf.emplace_back();
+            if (F.csg_nesting) {
+                // A plane's Hit::infinity carries Vertex::zero() as its position (hit.rs:37-52) and Triangle::intersect puts
+                // it through the same-side test like any other hit (triangle_object.rs:134-150): whether it passes depends on
+                // the triangle alone.  Only a CSG merge can see such a hit (select_first_hit wants distance < f32::MAX).
+                for (uint32_t k = 0; k < n; k++) {
+                    const TriHot &t = F.tris[mi.tri_first + k];
+                    f3 a = mk3(t.a_nx.x, t.a_nx.y, t.a_nx.z), b = mk3(t.b_ny.x, t.b_ny.y, t.b_ny.z), c = mk3(t.c_nz.x, t.c_nz.y, t.c_nz.z);
+                    f3 z = mk3(0.0f, 0.0f, 0.0f);
+                    f3 ai = z - a, bi = z - b, ci = z - c;
+                    f3 ab = b - a, bc = c - b, ca = a - c;
+                    f3 ab_n = cross3(ai, ab), bc_n = cross3(bi, bc), ca_n = cross3(ci, ca);
+                    if (dot3(ab_n, bc_n) > 0.0f && dot3(bc_n, ca_n) > 0.0f) F.mesh_inf.back().push_back(k);
+                }
+            }
             F.tri_normals.insert(F.tri_normals.end(), o.tri_nrm.begin(), o.tri_nrm.end());
             push_rec(F, OP_MESH, o.material, (uint32_t)F.meshes.size());
             F.meshes.push_back(mi);
@@ -294,6 +311,7 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
         case RRT_OBJ_CSG: {
             // sub-trees that are CSG nodes themselves get their own bound when it is tighter than the enclosing one
             const HostObject *kids[2] = {o.left.get(), o.right.get()};
+            F.csg_nesting++;
             for (const HostObject *kid : kids) {
                 Box kb = bound_of(*kid);
                 bool own = g_bounds_enabled && kid->kind == RRT_OBJ_CSG && kb.finite && !same_box(kb, enclosing);
@@ -302,6 +320,7 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
                 emit(F, *kid, own ? kb : enclosing);
                 if (own) F.prog[at].aux = (uint32_t)F.prog.size() - first;
             }
+            F.csg_nesting--;
             push_rec(F, (uint32_t)(OP_CSG_UNION + o.csg_mode), -1, 0);
             break;
         }
@@ -371,7 +390,7 @@ int flatten_scene(rrt_scene *s) {
     F.bvh_builder = s->params.bvh_builder;
     g_bounds_enabled = getenv("RRT_NO_BOUNDS") == nullptr;  // debugging aid: the reference's plain all-objects loop
     uint32_t max_stack = 0;
-    bool has_csg = false, has_bounds = false;
+    bool has_csg = false, has_bounds = false, csg_mesh = false;
     for (size_t oi = 0; oi < s->objects.size(); oi++) {
         const HostObject &ho = *s->objects[oi];
         Box bb = bound_of(ho);
@@ -391,6 +410,7 @@ int flatten_scene(rrt_scene *s) {
         F.prog[first + count - 1].op |= PF_LAST;
         if (count > 1) {
             has_csg = true;
+            if (ho.contains_mesh()) csg_mesh = true;  // a mesh leaf: its BVH is walked while hit lists are live
             uint32_t sp = 0;
             for (uint32_t k = 0; k < count; k++) {
                 ProgRec &r = F.prog[first + k];
@@ -406,6 +426,12 @@ int flatten_scene(rrt_scene *s) {
     }
     for (const ProgRec &r : F.prog)  // sub-tree bounds inside a CSG program count too, not only whole-object bounds
         if ((r.op & 0xFFu) == OP_BOUND) has_bounds = true;
+    std::vector<uint32_t> mesh_inf(F.meshes.size() * 2, 0u);
+    for (size_t m = 0; m < F.mesh_inf.size(); m++) {
+        mesh_inf[2 * m] = (uint32_t)(mesh_inf.size() - 2 * F.meshes.size());
+        mesh_inf[2 * m + 1] = (uint32_t)F.mesh_inf[m].size();
+        mesh_inf.insert(mesh_inf.end(), F.mesh_inf[m].begin(), F.mesh_inf[m].end());
+    }
     if (getenv("RRT_DUMP_PROGRAM")) {  // debugging aid: the record stream, without touching the device
         static const char *names[] = {"plane", "sphere", "cuboid", "quadric", "mesh", "union", "intersection", "difference", "bound"};
         for (size_t k = 0; k < F.prog.size(); k++) {
@@ -422,7 +448,7 @@ int flatten_scene(rrt_scene *s) {
                 fwrite(hdr, sizeof(hdr), 1, f);
                 if (n) fwrite(p, elem, n, f);
             };
-            uint32_t misc[4] = {has_csg ? max_stack + 1 : 0u, F.bvh_depth ? F.bvh_depth + 1 : 0u, has_bounds ? 1u : 0u, has_csg ? 1u : 0u};
+            uint32_t misc[4] = {has_csg ? max_stack + 1 : 0u, F.bvh_depth ? F.bvh_depth + 1 : 0u, has_bounds ? 1u : 0u, (has_csg ? 1u : 0u) | (csg_mesh ? 2u : 0u)};
             put(misc, 4, 4);
             put(F.prog.data(), sizeof(ProgRec), F.prog.size());
             put(F.plane_cold.data(), sizeof(PlaneCold), F.plane_cold.size());
@@ -431,6 +457,7 @@ int flatten_scene(rrt_scene *s) {
             put(F.tri_index.data(), 4, F.tri_index.size());
             put(F.tri_normals.data(), 4, F.tri_normals.size());
             put(F.nodes.data(), sizeof(BvhNodeQ), F.nodes.size());
+            put(mesh_inf.data(), 4, mesh_inf.size());
             fclose(f);
         }
     }
@@ -446,7 +473,8 @@ int flatten_scene(rrt_scene *s) {
     D.bvh_stack = F.bvh_depth ? F.bvh_depth + 1 : 0;
     size_t list_bytes = (size_t)D.lds_slots * 6 /* HitVec capacity */ * 256 * 8;
     size_t stack_bytes = (size_t)((D.bvh_stack + 1) / 2) * 256 * 8;  // two stack words per 8-byte column element (dev_trace.h Lds)
-    D.lds_bytes = std::max(list_bytes, stack_bytes);
+    // the stack aliases the hit lists (a lane never needs both at once) unless a CSG tree has a mesh leaf
+    D.lds_bytes = csg_mesh ? list_bytes + stack_bytes : std::max(list_bytes, stack_bytes);
     if (D.lds_bytes > 160 * 1024) return fail(RRT_ERR_LIMIT, "per-block LDS need exceeds 160 KiB (BVH too deep)");
     D.flops_per_trace = F.flops;
     if (getenv("RRT_BVH_INFO"))
@@ -502,6 +530,7 @@ int flatten_scene(rrt_scene *s) {
     UP(tri_index, F.tri_index)
     UP(tri_normals, F.tri_normals)
     UP(nodes, F.nodes)
+    UP(mesh_inf, mesh_inf)
     UP(materials, mats)
     UP(textures, texs)
     UP(texels8, t8)
@@ -513,7 +542,7 @@ int flatten_scene(rrt_scene *s) {
     V.n_prog = (uint32_t)F.prog.size();
     V.n_objects = (uint32_t)s->objects.size();
     V.n_lights = (uint32_t)lights.size();
-    V.has_csg = has_csg ? 1 : 0;
+    V.has_csg = (has_csg ? 1u : 0u) | (csg_mesh ? 2u : 0u);
     V.has_bounds = has_bounds ? 1 : 0;
     V.n_plane_cold = (uint32_t)F.plane_cold.size();
     V.n_meshes = (uint32_t)F.meshes.size();
@@ -524,6 +553,7 @@ int flatten_scene(rrt_scene *s) {
     V.tri_index = D.tri_index.p;
     V.tri_normals = D.tri_normals.p;
     V.nodes = D.nodes.p;
+    V.mesh_inf = D.mesh_inf.p;
     V.materials = D.materials.p;
     V.textures = D.textures.p;
     V.texels8 = D.texels8.p;
@@ -1218,8 +1248,6 @@ int rrt_object_define(rrt_scene *s, const rrt_object_desc *d) {
             if (d->left < 0 || d->left >= n || d->right < 0 || d->right >= n || d->left == d->right || !s->detached[d->left] ||
                 !s->detached[d->right])
                 return fail(RRT_ERR_INVALID, "bad csg child handle");
-            if (s->detached[d->left]->contains_mesh() || s->detached[d->right]->contains_mesh())
-                return fail(RRT_ERR_LIMIT, "meshes cannot be CSG children in this build");
             o->csg_mode = d->csg_mode;
             o->left = std::move(s->detached[d->left]);
             o->right = std::move(s->detached[d->right]);

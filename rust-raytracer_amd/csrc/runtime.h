@@ -65,6 +65,7 @@ struct DeviceScene {
     DBuf<uint32_t> tri_index;
     DBuf<float> tri_normals;
     DBuf<BvhNodeQ> nodes;
+    DBuf<uint32_t> mesh_inf;
     DBuf<DevMaterial> materials;
     DBuf<DevTexture> textures;
     DBuf<uchar4> texels8;

@@ -221,3 +221,53 @@ def random_scene(scene, seed, with_mesh=True):
         scene.add_object(mesh(scene, tris, None, mats[0], False))
     light(scene, abi.LIGHT_POINT, position=tuple(u(-4.0, 4.0, 3)), colour=(1.0, 1.0, 1.0))
     return scene
+
+
+def csg_mesh_scene(scene, seed):
+    """CSG trees with MESH leaves (csg_object.rs:25-36 takes any Box<dyn Object>; PolyMesh::intersect hands the merge at
+    most one hit, polymesh_object.rs:216-242): a closed box mesh and a triangle soup combined with spheres, cuboids and each
+    other in all three modes, next to plain objects."""
+    rng = np.random.default_rng(seed)
+    u = lambda lo, hi, n=None: rng.uniform(lo, hi, n).astype(np.float32) if n else np.float32(rng.uniform(lo, hi))
+    mats = [monochrome(scene, tuple(u(0.1, 1.0, 3)), 0.1, 50.0) for _ in range(2)]
+    mats.append(compound(scene, [monochrome(scene, (0.5, 0.5, 0.8)), global_material(scene, 0.5, 0.0, 1.0)]))
+
+    def box_mesh(c, s):
+        x0, y0, z0 = c
+        x1, y1, z1 = c + s
+        v = np.array([[x0, y0, z0], [x1, y0, z0], [x1, y1, z0], [x0, y1, z0], [x0, y0, z1], [x1, y0, z1], [x1, y1, z1], [x0, y1, z1]], np.float32)
+        f = [(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (3, 7, 6), (3, 6, 2), (0, 4, 7), (0, 7, 3), (1, 2, 6), (1, 6, 5)]
+        return mesh(scene, v[np.array(f)], None, mats[int(rng.integers(0, 3))], False)
+
+    def soup():
+        n_tri = int(rng.integers(6, 40))
+        tris = u(-1.5, 1.5, (n_tri, 1, 3)) + u(-0.7, 0.7, (n_tri, 3, 3))
+        return mesh(scene, tris, None, mats[int(rng.integers(0, 3))], False)
+
+    def leaf():
+        k = int(rng.integers(0, 4))
+        c = u(-1.5, 1.5, 3)
+        if k == 0:
+            return box_mesh(c - 0.5, u(0.5, 1.6, 3))
+        if k == 1:
+            return soup()
+        if k == 2:
+            return sphere(scene, tuple(c), float(u(0.4, 1.2)), mats[int(rng.integers(0, 3))])
+        return cuboid(scene, tuple(c - 0.5), tuple(u(0.4, 1.5, 3)), mats[int(rng.integers(0, 3))])
+
+    def tree(depth):
+        if depth == 0:
+            return leaf()
+        return csg(scene, int(rng.integers(0, 3)), tree(depth - 1), tree(depth - 1))
+
+    for _ in range(int(rng.integers(3, 6))):
+        h = tree(int(rng.integers(1, 3)))
+        t = rng.integers(0, 3)
+        if t == 1:
+            scene.object_transform(h, translation(tuple(u(-1.0, 1.0, 3))))
+        elif t == 2:
+            scene.object_transform(h, scaling(float(u(0.7, 1.5))))
+        scene.add_object(h)
+    scene.add_object(sphere(scene, tuple(u(-2.0, 2.0, 3)), 0.5, mats[0]))
+    light(scene, abi.LIGHT_POINT, position=tuple(u(-4.0, 4.0, 3)), colour=(1.0, 1.0, 1.0))
+    return scene

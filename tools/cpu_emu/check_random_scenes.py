@@ -47,13 +47,14 @@ for seed in seeds:
         print("teapots: mesh hits %.2f mismatches (id, t, prim, shadow) %s" % ((c["object_id"] == 0).mean(), mism))
         bad += any(mism)
         continue
-    gpu = kit.random_scene(rrt.Scene(), seed)
+    make_scene = kit.csg_mesh_scene if os.environ.get("EMU_SCENE") == "csgmesh" else kit.random_scene   # csgmesh: CSG trees with mesh leaves
+    gpu = make_scene(rrt.Scene(), seed)
     try:
         gpu.pre_render(1)   # dumps the arrays, then fails for want of a GPU (or succeeds on a GPU box)
     except rrt.RrtError as e:
         if e.code != abi.ERR_DEVICE:
             print("seed", seed, "flatten refused:", e); continue
-    cpu = kit.random_scene(ob.OracleScene(), seed)
+    cpu = make_scene(ob.OracleScene(), seed)
     make_rays = kit.coherent_rays if os.environ.get("EMU_COHERENT") else kit.random_rays   # coherent: the wave cull bites
     o, d = make_rays(int(os.environ.get("EMU_RAYS", "2000")), seed, origin_scale=5.0, towards=(0.0, 0.0, 0.0), spread=3.0)
     np.concatenate([o, d], axis=1).astype(np.float32).tofile(os.path.join(tmp, "rays.f32"))

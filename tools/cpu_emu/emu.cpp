@@ -115,12 +115,14 @@ int main(int argc, char **argv) {
     auto tri_index = get<uint32_t>(f);
     auto tri_normals = get<float>(f);
     auto nodes = get<BvhNodeQ>(f);
+    auto mesh_inf = get<uint32_t>(f);
     fclose(f);
     DevScene S;
     memset(&S, 0, sizeof(S));
     S.prog = prog.data(); S.n_prog = (uint32_t)prog.size(); S.has_bounds = misc[2]; S.has_csg = misc[3];
     S.plane_cold = plane_cold.data(); S.meshes = meshes.data(); S.tris = tris.data(); S.tri_index = tri_index.data();
-    S.tri_normals = tri_normals.data(); S.nodes = nodes.data();
+    S.tri_normals = tri_normals.data(); S.nodes = nodes.data(); S.mesh_inf = mesh_inf.data();
+    S.n_plane_cold = (uint32_t)plane_cold.size(); S.n_meshes = (uint32_t)meshes.size();
     FILE *r = fopen(argv[2], "rb");
     fseek(r, 0, SEEK_END); long bytes = ftell(r); fseek(r, 0, SEEK_SET);
     std::vector<float> rays(bytes / 4);
@@ -136,7 +138,8 @@ int main(int argc, char **argv) {
     // 64 lane threads live for the whole run; a std::barrier separates waves and phases (trace, then shadowtrace)
     const uint32_t BLOCK = 256;
     size_t list_bytes = (size_t)misc[0] * 6 * BLOCK * 8, stack_bytes = (size_t)((misc[1] + 1) / 2) * BLOCK * 8;
-    g_lds_elems = std::max(list_bytes, stack_bytes) / 8;
+    const bool csg_mesh = (misc[3] & 2u) != 0;  // a mesh leaf in a CSG tree: the stack lies behind the hit lists
+    g_lds_elems = (csg_mesh ? list_bytes + stack_bytes : std::max(list_bytes, stack_bytes)) / 8;
     // ONE buffer, laid out and sized as runtime.cpp does for a 256-thread block (lists and BVH stack alias); the wave
     // emulated here plays lanes 64..127 of that block.  Refilled with garbage for every wave, as on the device.
     std::vector<float2> lists(std::max<size_t>(g_lds_elems, 1));
@@ -159,6 +162,7 @@ int main(int argc, char **argv) {
                     if (lane < lanes) {
                         size_t i = base + lane;
                         Lds lds; lds.le = lists.data(); lds.stack = reinterpret_cast<int *>(lists.data()); lds.nthreads = BLOCK; lds.tid = (64u + (uint32_t)lane) % BLOCK;
+                        lds.stack_base = csg_mesh ? misc[0] * RRT_LIST_CAP : 0u;
                         Counters cnt = {0, 0, 0, 0};
                         f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
                         if (phase == 0) {
@@ -172,13 +176,14 @@ int main(int argc, char **argv) {
                             if (tr.object != 0xFFFFFFFFu) {
                                 const ProgRec &in = S.prog[tr.instr];
                                 uint32_t op = in.op & 0xFFu;
-                                if (op == OP_MESH) {
-                                    prim = S.tri_index[S.meshes[in.aux].tri_first + tr.sub];
-                                } else if (in.op & PF_CSG) {
+                                if (in.op & PF_CSG) {
+                                    if (op == OP_MESH && tr.sub >= S.meshes[in.aux].tri_count) abort();  // the winner's triangle
                                     for (uint32_t k = tr.instr; !(S.prog[k].op & PF_FIRST);) {
                                         k--;
                                         if ((S.prog[k].op & 0xFFu) < OP_CSG_UNION) prim++;
                                     }
+                                } else if (op == OP_MESH) {
+                                    prim = S.tri_index[S.meshes[in.aux].tri_first + tr.sub];
                                 } else if (op == OP_CUBOID) {
                                     prim = tr.sub;
                                     if (in.aux + (tr.sub >> 1) >= plane_cold.size()) abort();
