@@ -308,14 +308,16 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
     LaneStack<PLAIN_STACK> stack{lds, 0u};
     int cur = 0;  // root
     if (tri_count == 0) return false;
+    // "while-while" order: a lane descends through inner nodes until it holds a leaf (or is done); the wave leaves the
+    // inner loop when no lane has a node left, and only then are the leaves' triangles tested, by all lanes that hold one.
+    const int DONE = (int)0x80000000;  // as a leaf code its first triangle is beyond every mesh
     for (;;) {
-        if (cur >= 0) {
-            if ((uint32_t)cur >= node_count) {  // index guard: refuse a wild node id instead of faulting the GPU
-                cnt.overflow |= 16u;              // RRT_ERR_BIT_INTERNAL
+        while (cur >= 0) {
+            if ((uint32_t)cur >= node_count) {
+                cnt.overflow |= 16u;
+                cur = DONE;
                 break;
             }
-            // 64 bytes per node and fewer than 2^26 nodes per mesh: the byte offset fits 32 bits, so the load can take the
-            // mesh's base from SGPRs and ONE vector register of offset (no 64-bit address arithmetic per visit)
             const BvhNodeQ N = *reinterpret_cast<const BvhNodeQ *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)cur << 6));
             int c0 = N.child[0], c1 = N.child[1], c2 = N.child[2], c3 = N.child[3];
             float k0, k1, k2, k3;
@@ -323,30 +325,30 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
             const bool h1 = box_test(N.q[1], N.q[5], N.q[9], slabs, best, k1);
             const bool h2 = box_test(N.q[2], N.q[6], N.q[10], slabs, best, k2);
             const bool h3 = box_test(N.q[3], N.q[7], N.q[11], slabs, best, k3);
-            cnt.nodes += 4;  // box tests executed (an empty slot's inside-out box is tested like any other)
-            if (h0 || h1 || h2 || h3) {
-                // Nearest first, the others on the stack farthest first.  A miss gets the key +inf and sorts behind every
-                // hit; what still has the key +inf afterwards is not visited (a box first met at +inf holds nothing a ray
-                // could hit before `best`).  An empty slot of a wild mesh "hits" too: its code is a leaf of no triangles.
-                k0 = h0 ? k0 : RRT_INF, k1 = h1 ? k1 : RRT_INF, k2 = h2 ? k2 : RRT_INF, k3 = h3 ? k3 : RRT_INF;
-                order2(k0, c0, k1, c1);
-                order2(k2, c2, k3, c3);
-                order2(k0, c0, k2, c2);
-                order2(k1, c1, k3, c3);
-                order2(k1, c1, k2, c2);
-                if (k3 < RRT_INF) stack.push(c3);
-                if (k2 < RRT_INF) stack.push(c2);
-                if (k1 < RRT_INF) stack.push(c1);
-                if (k0 < RRT_INF) {
-                    cur = c0;
-                    continue;
-                }
-            }
-        } else {
+            cnt.nodes += 4;
+            k0 = h0 ? k0 : RRT_INF, k1 = h1 ? k1 : RRT_INF, k2 = h2 ? k2 : RRT_INF, k3 = h3 ? k3 : RRT_INF;
+            order2(k0, c0, k1, c1);
+            order2(k2, c2, k3, c3);
+            order2(k0, c0, k2, c2);
+            order2(k1, c1, k3, c3);
+            order2(k1, c1, k2, c2);
+            if (k3 < RRT_INF) stack.push(c3);
+            if (k2 < RRT_INF) stack.push(c2);
+            if (k1 < RRT_INF) stack.push(c1);
+            if (k0 < RRT_INF)
+                cur = c0;
+            else if (stack.empty())
+                cur = DONE;
+            else
+                cur = stack.pop();
+        }
+        if (cur == DONE) break;
+        {
             uint32_t code = (uint32_t)(-(cur + 1));
             uint32_t first = code >> 4, n = code & 15u;
-            if (first + n > tri_count) {  // index guard, as above
+            if (first + n > tri_count) {
                 cnt.overflow |= 16u;
+                cur = DONE;  // index guard, as above: give up the walk
                 break;
             }
             for (uint32_t k = 0; k < n; k++) {

@@ -6,6 +6,6 @@ for v in "$@"; do
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        j=json.loads(l); print('Mrays/s %.0f ms/step %.3f kernel_ms %.3f frac %.4f'%(j['value'],j['ms_per_step'],j['roofline']['kernel_ms_per_frame'],j['roofline']['frac']))
+        j=json.loads(l); print('Mrays/s %.0f ms/step %.3f kernel_ms %.3f frac %.4f'%(j['value'],j['ms_per_step'],j['roofline']['kernel_ms_per_launch'],j['roofline']['frac']))
 " || exit 1
 done
