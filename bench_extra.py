@@ -151,7 +151,7 @@ def run_mesh(rrt, torch, steps=5, bvh_builder=0):
         "hit_fraction": float((ids >= 0).float().mean().item()),
         "bvh_nodes_per_ray": st["bvh_nodes_visited"] / (st["rays_primary"] + st["rays_shadow"]),
         "bvh_tris_per_ray": st["bvh_tris_tested"] / (st["rays_primary"] + st["rays_shadow"]),
-        "bvh_builder": "device LBVH" if bvh_builder else "host binned SAH",
+        "bvh_builder": ("host binned SAH", "device LBVH", "device binned SAH")[bvh_builder],
         "ms_bvh_build": st["ms_bvh_build"],
         "host_seconds": {"mesh_generation": t_build_host, "pre_render_incl_bvh_build": t_pre},
         "roofline": {"kernel": "k_trace_shade", "bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
@@ -330,6 +330,8 @@ if __name__ == "__main__":
         res["mesh_1m"] = run_mesh(rrt, torch)
     if which in ("all", "mesh_lbvh"):
         res["mesh_1m_device_lbvh"] = run_mesh(rrt, torch, bvh_builder=1)
+    if which in ("all", "mesh_dsah"):
+        res["mesh_1m_device_sah"] = run_mesh(rrt, torch, bvh_builder=2)
     if which in ("all", "photon"):
         res["photon_1m"] = run_photon(rrt, torch)
     if which in ("all", "csg"):

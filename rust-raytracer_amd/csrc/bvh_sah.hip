@@ -1,0 +1,554 @@
+// bvh_sah.hip — the host's binned-SAH BVH2 build (bvh_build.cpp) on the device, level by level.
+// Selected with rrt_params.bvh_builder = RRT_BVH_DEVICE_SAH.  Same bins (16 per axis over the node's centroid bounds), same
+// cost expression, same tie rule, same leaf size, evaluated with the same f32 operations: the tree is the one build_bvh
+// makes (node numbering aside, which quantise_bvh does not look at), so frames cost what they cost with the host's tree,
+// and the build runs where the triangles already are.
+//
+// One level of the tree per round, all of its nodes at once:
+//   bin      every triangle of a node with more than kLeafMax triangles grows the bin of its centroid on each axis
+//            (atomics on order-preserving words; a wave whose 1024 positions lie in ONE node collects them in LDS first)
+//   decide   one thread per node: sweep the 3 x 15 candidate planes as the host does, create the two children
+//   flag     which side each triangle goes to; exclusive scan of the flags (rocPRIM)
+//   scatter  stable partition of every node's range at once (position = range start + rank on its side), the children's
+//            centroid bounds collected on the way
+// The host reads one word per level (how many nodes the level created) and stops when it is zero.
+//
+// Memory is spent freely (MI355X: 288 GB): 2n node records, one 1344-byte bin block per node of the widest level.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+
+#include <rocprim/rocprim.hpp>
+
+#include "bvh_lbvh.h"
+#include "runtime.h"
+
+namespace rrt {
+
+namespace {
+
+using lbvh::ordered;
+using lbvh::unordered;
+
+constexpr int kBlock = 256;
+constexpr uint32_t kLeafMax = 4;  // bvh_build.cpp
+constexpr int kBins = 16;         // bvh_build.cpp
+constexpr uint32_t kChunk = 512;  // positions per wave in the binning and scatter kernels
+constexpr uint32_t kBinWords = 3 * kBins * 7;  // per node: [axis][bin] lo xyz, hi xyz (ordered words), count
+inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + kBlock - 1) / kBlock)); }
+
+struct Node {
+    uint32_t lo, hi;      // positions [lo, hi) of `order`
+    int32_t left;         // index of the left child (right = left + 1), -1: leaf, -2: not decided yet
+    uint32_t n_left;      // triangles that go left
+    int32_t axis, split;  // axis < 0: no plane found (all centroids coincide), split by position at lo + n_left
+    uint32_t box[6];      // ordered words: lo xyz, hi xyz of the triangles' boxes
+    uint32_t cb[6];       // same for their centroids
+};
+
+// empty-aware decode: 0xFFFFFFFF / 0 are the "nothing seen" values of a lower / upper word
+__device__ __forceinline__ float dec_lo(uint32_t u) { return u == 0xFFFFFFFFu ? __builtin_huge_valf() : unordered(u); }
+__device__ __forceinline__ float dec_hi(uint32_t u) { return u == 0u ? -__builtin_huge_valf() : unordered(u); }
+
+// 0. triangle boxes and centroids (bvh_build.cpp:75-81), root box and centroid bounds; flags non-finite input
+__global__ __launch_bounds__(kBlock) void k_sah_prepare(const float *positions, uint32_t n, float *tb, float *cen, uint32_t *order, uint32_t *node_of,
+                                                        Node *nodes, uint32_t *err) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c0 = (blockIdx.x * (kBlock / 64) + wave) * kChunk;  // one wave per kChunk triangles: 12 atomics per wave on the root
+    const uint32_t c1 = min(c0 + kChunk, n);
+    uint32_t w[12];
+    for (int k = 0; k < 3; k++) w[k] = w[6 + k] = 0xFFFFFFFFu, w[3 + k] = w[9 + k] = 0u;
+    bool bad = false;
+    for (uint32_t i = c0 + lane; i < c1; i += 64) {
+        const float *p = positions + (size_t)i * 9;
+        for (int a = 0; a < 3; a++) {
+            float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+            for (int c = 0; c < 3; c++) {
+                lo = fminf(lo, p[c * 3 + a]);
+                hi = fmaxf(hi, p[c * 3 + a]);
+                if (!(fabsf(p[c * 3 + a]) < __builtin_huge_valf())) bad = true;
+            }
+            const float ce = 0.5f * (lo + hi);
+            if (!(fabsf(ce) < __builtin_huge_valf())) bad = true;
+            tb[(size_t)i * 6 + a] = lo;
+            tb[(size_t)i * 6 + 3 + a] = hi;
+            cen[(size_t)i * 3 + a] = ce;
+            w[a] = min(w[a], ordered(lo)), w[3 + a] = max(w[3 + a], ordered(hi));
+            w[6 + a] = min(w[6 + a], ordered(ce)), w[9 + a] = max(w[9 + a], ordered(ce));
+        }
+        order[i] = i;
+        node_of[i] = 0;
+    }
+    if (bad) atomicOr(err, 1u);
+    if (c0 >= n) return;  // whole waves only: the butterflies below have every lane
+    for (int k = 0; k < 12; k++) {
+        const bool is_lo = (k % 6) < 3;
+        uint32_t v = w[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+            v = is_lo ? min(v, o) : max(v, o);
+        }
+        if (lane == 0) {
+            uint32_t *dst = k < 6 ? &nodes[0].box[k] : &nodes[0].cb[k - 6];
+            if (is_lo)
+                atomicMin(dst, v);
+            else
+                atomicMax(dst, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sah_clear_bins(uint32_t *bins, uint64_t words) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < words) bins[i] = (i % 7) < 3 ? 0xFFFFFFFFu : 0u;  // lower words, then upper words and the count
+}
+
+__device__ __forceinline__ int bin_of(float c, float lo, float scale) {
+    int b = (int)((c - lo) * scale);  // bvh_build.cpp:116
+    return min(max(b, 0), kBins - 1);
+}
+
+// 1. binning.  One wave per kChunk positions.  The part of a node that lies in the chunk is a run of positions; a run of
+// kLongRun or more is collected in the wave's LDS bins first and only the bins it touched go to memory (a top-level node
+// would otherwise put 21 atomics per triangle on the same eleven cache lines); shorter runs use the atomics directly.
+constexpr uint32_t kLongRun = 64;
+__device__ __forceinline__ bool splits(const Node &N) { return N.left == -2 && N.hi - N.lo > kLeafMax; }
+__device__ __forceinline__ void bin_triangle(uint32_t *bins_of_node, const Node &N, const float *tb, const float *cen, uint32_t t) {
+    uint32_t bw[6];
+    for (int k = 0; k < 6; k++) bw[k] = ordered(tb[(size_t)t * 6 + k]);
+    for (int a = 0; a < 3; a++) {
+        const float clo = dec_lo(N.cb[a]);
+        const float ext = dec_hi(N.cb[3 + a]) - clo;
+        if (!(ext > 0.0f)) continue;
+        uint32_t *d = bins_of_node + (a * kBins + bin_of(cen[(size_t)t * 3 + a], clo, (float)kBins / ext)) * 7;
+        for (int k = 0; k < 3; k++) atomicMin(d + k, bw[k]);
+        for (int k = 3; k < 6; k++) atomicMax(d + k, bw[k]);
+        atomicAdd(d + 6, 1u);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_sah_bin(const uint32_t *order, const uint32_t *node_of, const Node *nodes, const float *tb, const float *cen,
+                                                    uint32_t n, uint32_t level_first, uint32_t *bins) {
+    __shared__ uint32_t s_bins[kBlock / 64][kBinWords];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c0 = (blockIdx.x * (kBlock / 64) + wave) * kChunk;
+    if (c0 >= n) return;  // no block-wide barrier below: waves are on their own
+    const uint32_t c1 = min(c0 + kChunk, n);
+    // long runs: any run of kLongRun positions holds one of the sampled positions
+    bool long_here = false;
+    for (uint32_t i = c0 + lane * (kLongRun / 2); i < c1; i += 64 * (kLongRun / 2)) {
+        const Node N = nodes[node_of[i]];
+        if (splits(N) && min(N.hi, c1) - max(N.lo, c0) >= kLongRun) long_here = true;
+    }
+    if (__any(long_here)) {
+        uint32_t *sb = s_bins[wave];
+        for (uint32_t pos = c0; pos < c1;) {  // wave-uniform walk over the runs
+            const uint32_t node = node_of[pos];
+            const Node N = nodes[node];
+            const uint32_t end = min(N.hi, c1);
+            if (end <= pos) break;  // cannot be (pos lies in N's range); never loop for ever
+            if (splits(N) && end - max(N.lo, c0) >= kLongRun) {
+                for (uint32_t k = lane; k < kBinWords; k += 64) sb[k] = (k % 7) < 3 ? 0xFFFFFFFFu : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = pos + lane; i < end; i += 64) bin_triangle(sb, N, tb, cen, order[i]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                uint32_t *g = bins + (size_t)(node - level_first) * kBinWords;
+                for (uint32_t k = lane; k < kBinWords; k += 64) {
+                    const uint32_t f = k % 7, v = sb[k];
+                    if (f < 3) {
+                        if (v != 0xFFFFFFFFu) atomicMin(g + k, v);
+                    } else if (v != 0u) {
+                        if (f < 6)
+                            atomicMax(g + k, v);
+                        else
+                            atomicAdd(g + k, v);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            pos = end;
+        }
+    }
+    for (uint32_t i = c0 + lane; i < c1; i += 64) {  // the short runs
+        const uint32_t node = node_of[i];
+        const Node N = nodes[node];
+        if (!splits(N) || min(N.hi, c1) - max(N.lo, c0) >= kLongRun) continue;
+        bin_triangle(bins + (size_t)(node - level_first) * kBinWords, N, tb, cen, order[i]);
+    }
+}
+
+struct FBox {
+    float lo[3], hi[3];
+    __device__ void reset() {
+        for (int a = 0; a < 3; a++) lo[a] = __builtin_huge_valf(), hi[a] = -__builtin_huge_valf();
+    }
+    __device__ void grow(const FBox &b) {
+        for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], b.lo[a]), hi[a] = fmaxf(hi[a], b.hi[a]);
+    }
+    __device__ float half_area() const {  // bvh_build.cpp:42-46
+        const float e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+        if (e0 < 0 || e1 < 0 || e2 < 0) return 0.0f;
+        return e0 * e1 + e1 * e2 + e2 * e0;
+    }
+};
+__device__ __forceinline__ FBox load_bin(const uint32_t *d) {
+    FBox b;
+    for (int k = 0; k < 3; k++) b.lo[k] = dec_lo(d[k]), b.hi[k] = dec_hi(d[3 + k]);
+    return b;
+}
+
+// 2. the split of every node of the level (bvh_build.cpp:94-170), and its two children
+__global__ __launch_bounds__(kBlock) void k_sah_decide(Node *nodes, uint32_t level_first, uint32_t level_count, const uint32_t *bins, uint32_t next_first,
+                                                       uint32_t capacity, uint32_t *created, uint32_t *err) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= level_count) return;
+    Node &N = nodes[level_first + k];
+    const uint32_t cnt = N.hi - N.lo;
+    if (cnt <= kLeafMax) {
+        N.left = -1;
+        return;
+    }
+    const uint32_t *B = bins + (size_t)k * kBinWords;
+    int best_axis = -1, best_split = -1;
+    float best_cost = __builtin_huge_valf();
+    for (int a = 0; a < 3; a++) {
+        const float ext = dec_hi(N.cb[3 + a]) - dec_lo(N.cb[a]);
+        if (!(ext > 0.0f)) continue;
+        const uint32_t *A = B + a * kBins * 7;
+        float right_area[kBins];
+        uint32_t right_cnt[kBins];
+        FBox acc;
+        acc.reset();
+        uint32_t c = 0;
+        for (int b = kBins - 1; b > 0; b--) {
+            acc.grow(load_bin(A + b * 7));
+            c += A[b * 7 + 6];
+            right_area[b] = acc.half_area();
+            right_cnt[b] = c;
+        }
+        acc.reset();
+        c = 0;
+        for (int b = 0; b < kBins - 1; b++) {
+            acc.grow(load_bin(A + b * 7));
+            c += A[b * 7 + 6];
+            if (c == 0 || right_cnt[b + 1] == 0) continue;
+            const float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_axis = a;
+                best_split = b;
+            }
+        }
+    }
+    const uint32_t pair = atomicAdd(created, 2u);
+    if (next_first + pair + 2u > capacity) {  // cannot happen (a binary tree over n leaves has fewer than 2n nodes); refuse rather than overrun
+        atomicOr(err, 2u);
+        N.left = -1;
+        return;
+    }
+    Node L, R;
+    for (int q = 0; q < 3; q++) L.box[q] = R.box[q] = L.cb[q] = R.cb[q] = 0xFFFFFFFFu, L.box[3 + q] = R.box[3 + q] = L.cb[3 + q] = R.cb[3 + q] = 0u;
+    uint32_t n_left;
+    if (best_axis < 0) {
+        n_left = cnt / 2;  // bvh_build.cpp:148; the children's boxes are collected by the scatter
+    } else {
+        const uint32_t *A = B + best_axis * kBins * 7;
+        n_left = 0;
+        for (int b = 0; b < kBins; b++) {
+            Node &D = b <= best_split ? L : R;
+            for (int q = 0; q < 3; q++) D.box[q] = min(D.box[q], A[b * 7 + q]), D.box[3 + q] = max(D.box[3 + q], A[b * 7 + 3 + q]);
+            if (b <= best_split) n_left += A[b * 7 + 6];
+        }
+        if (n_left == 0 || n_left >= cnt) {  // the bins and the range disagree: internal error
+            atomicOr(err, 4u);
+            n_left = cnt / 2;
+        }
+    }
+    L.lo = N.lo, L.hi = R.lo = N.lo + n_left, R.hi = N.hi;
+    L.left = R.left = -2;
+    L.n_left = R.n_left = 0;
+    L.axis = R.axis = -1, L.split = R.split = 0;
+    N.left = (int32_t)(next_first + pair);
+    N.n_left = n_left;
+    N.axis = best_axis;
+    N.split = best_split;
+    nodes[next_first + pair] = L;
+    nodes[next_first + pair + 1] = R;
+}
+
+// 3. side of every triangle of a node that splits: 1 = left
+__global__ __launch_bounds__(kBlock) void k_sah_flag(const uint32_t *order, const uint32_t *node_of, const Node *nodes, const float *cen, uint32_t n,
+                                                     uint32_t *flag) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Node N = nodes[node_of[i]];
+    uint32_t f = 0;
+    if (N.left >= 0) {
+        if (N.axis < 0) {
+            f = i < N.lo + N.n_left ? 1u : 0u;
+        } else {
+            const float clo = dec_lo(N.cb[N.axis]);
+            const float ext = dec_hi(N.cb[3 + N.axis]) - clo;
+            f = bin_of(cen[(size_t)order[i] * 3 + N.axis], clo, (float)kBins / ext) <= N.split ? 1u : 0u;  // bvh_build.cpp:153-157
+        }
+    }
+    flag[i] = f;
+}
+
+// 4. stable partition of all ranges; the children's centroid bounds (and, for position splits, their boxes).  Runs as in
+// k_sah_bin: a long run reduces its centroids over the wave (12 atomics per run), short runs use the atomics directly.
+struct ScatterArgs {
+    const uint32_t *order, *node_of;
+    Node *nodes;
+    const float *tb, *cen;
+    const uint32_t *flag, *rank;
+    uint32_t *order_out, *node_out;
+};
+// moves position i of node N (which splits); returns the side (1 = left) and the centroid's ordered words
+__device__ __forceinline__ uint32_t scatter_one(const ScatterArgs &A, const Node &N, uint32_t i, uint32_t cw[3]) {
+    const uint32_t t = A.order[i];
+    const uint32_t f = A.flag[i];
+    const uint32_t lb = A.rank[i] - A.rank[N.lo];  // left-going triangles of this node in front of i
+    const uint32_t pos = f ? N.lo + lb : N.lo + N.n_left + (i - N.lo - lb);
+    const int32_t child = N.left + (f ? 0 : 1);
+    A.order_out[pos] = t;
+    A.node_out[pos] = (uint32_t)child;
+    for (int a = 0; a < 3; a++) cw[a] = ordered(A.cen[(size_t)t * 3 + a]);
+    if (N.axis < 0) {  // split by position: nobody has the children's boxes yet
+        Node &C = A.nodes[child];
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&C.box[a], ordered(A.tb[(size_t)t * 6 + a]));
+            atomicMax(&C.box[3 + a], ordered(A.tb[(size_t)t * 6 + 3 + a]));
+        }
+    }
+    return f;
+}
+__global__ __launch_bounds__(kBlock) void k_sah_scatter(ScatterArgs A, uint32_t n) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t c0 = (blockIdx.x * (kBlock / 64) + wave) * kChunk;
+    if (c0 >= n) return;
+    const uint32_t c1 = min(c0 + kChunk, n);
+    bool long_here = false;
+    for (uint32_t i = c0 + lane * (kLongRun / 2); i < c1; i += 64 * (kLongRun / 2)) {
+        const Node N = A.nodes[A.node_of[i]];
+        if (N.left >= 0 && min(N.hi, c1) - max(N.lo, c0) >= kLongRun) long_here = true;
+    }
+    if (__any(long_here)) {
+        for (uint32_t pos = c0; pos < c1;) {  // wave-uniform walk over the runs
+            const Node N = A.nodes[A.node_of[pos]];
+            const uint32_t end = min(N.hi, c1);
+            if (end <= pos) break;
+            if (N.left >= 0 && end - max(N.lo, c0) >= kLongRun) {
+                uint32_t acc[12];  // [side][lo xyz, hi xyz]
+                for (int k = 0; k < 12; k++) acc[k] = (k % 6) < 3 ? 0xFFFFFFFFu : 0u;
+                for (uint32_t i = pos + lane; i < end; i += 64) {
+                    uint32_t cw[3];
+                    uint32_t *d = acc + (scatter_one(A, N, i, cw) ? 0 : 6);
+                    for (int a = 0; a < 3; a++) d[a] = min(d[a], cw[a]), d[3 + a] = max(d[3 + a], cw[a]);
+                }
+                for (int k = 0; k < 12; k++) {
+                    const bool is_lo = (k % 6) < 3;
+                    uint32_t v = acc[k];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+                        v = is_lo ? min(v, o) : max(v, o);
+                    }
+                    if (lane == 0) {
+                        Node &C = A.nodes[N.left + k / 6];
+                        if (is_lo) {
+                            if (v != 0xFFFFFFFFu) atomicMin(&C.cb[k % 6], v);
+                        } else if (v != 0u) {
+                            atomicMax(&C.cb[k % 6], v);
+                        }
+                    }
+                }
+            }
+            pos = end;
+        }
+    }
+    for (uint32_t i = c0 + lane; i < c1; i += 64) {  // leaves and the short runs
+        const uint32_t node = A.node_of[i];
+        const Node N = A.nodes[node];
+        if (N.left < 0) {  // a leaf keeps its place
+            A.order_out[i] = A.order[i];
+            A.node_out[i] = node;
+            continue;
+        }
+        if (min(N.hi, c1) - max(N.lo, c0) >= kLongRun) continue;
+        uint32_t cw[3];
+        Node &C = A.nodes[N.left + (scatter_one(A, N, i, cw) ? 0 : 1)];
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&C.cb[a], cw[a]);
+            atomicMax(&C.cb[3 + a], cw[a]);
+        }
+    }
+}
+
+// 5. inner nodes -> BvhNode (bvh_build.cpp:276-290: padded boxes of both children)
+__global__ __launch_bounds__(kBlock) void k_sah_mark_inner(const Node *nodes, uint32_t total, uint32_t *inner) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < total) inner[i] = nodes[i].left >= 0 ? 1u : 0u;
+}
+__device__ __forceinline__ void padded_axis(uint32_t ulo, uint32_t uhi, float &lo, float &hi) {  // bvh_build.cpp:49-58
+    const float l = dec_lo(ulo), h = dec_hi(uhi);
+    const float mag = fmaxf(fmaxf(fabsf(l), fabsf(h)), h - l);
+    const float pad = mag * 1.52587890625e-5f + 1e-30f;
+    lo = l - pad;
+    hi = h + pad;
+}
+__global__ __launch_bounds__(kBlock) void k_sah_emit(const Node *nodes, uint32_t total, const uint32_t *inner, const uint32_t *index, uint32_t n,
+                                                     BvhNode *out, uint32_t *err) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total || !inner[i]) return;
+    const Node N = nodes[i];
+    if ((uint32_t)N.left + 1u >= total) {
+        atomicOr(err, 8u);
+        return;
+    }
+    BvhNode nd;
+    float lo[2][3], hi[2][3];
+    for (int c = 0; c < 2; c++) {
+        const Node C = nodes[N.left + c];
+        for (int a = 0; a < 3; a++) padded_axis(C.box[a], C.box[3 + a], lo[c][a], hi[c][a]);
+        const bool child_inner = C.left >= 0;
+        if (C.lo >= C.hi || C.hi > n || (!child_inner && C.hi - C.lo > kLeafMax)) atomicOr(err, 16u);
+        nd.child[c] = child_inner ? (int32_t)index[N.left + c] : ~(int32_t)C.lo;
+        nd.cnt[c] = child_inner ? 0u : C.hi - C.lo;
+    }
+    nd.lo_x_hi_x = make_float4(lo[0][0], lo[1][0], hi[0][0], hi[1][0]);
+    nd.lo_y_hi_y = make_float4(lo[0][1], lo[1][1], hi[0][1], hi[1][1]);
+    nd.lo_z_hi_z = make_float4(lo[0][2], lo[1][2], hi[0][2], hi[1][2]);
+    out[index[i]] = nd;
+}
+
+}  // namespace
+
+// positions: host [n][3][3].  Outputs as build_bvh (bvh_build.cpp).  n > kLeafMax.  RRT_ERR_UNSUPPORTED_INPUT (returned as
+// +1, not an rrt error code) = a coordinate is not finite: the caller uses the host builder, whose "wild mesh" rules apply.
+int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
+                         float *device_ms) {
+    if (n <= kLeafMax) return fail(RRT_ERR_INVALID, "device BVH build needs more than 4 triangles");
+    if (n >= (1u << 27)) return fail(RRT_ERR_LIMIT, "more than 2^27 triangles in one mesh");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(RRT_ERR_DEVICE, "no HIP device: the device BVH builder has no CPU fallback");
+    const bool timing = getenv("RRT_LBVH_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sah] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count());
+        T0 = t;
+    };
+    const uint32_t capacity = 2 * n;           // node records
+    const uint32_t bin_slots = n / 2 + 64;     // nodes of one level (each inner node of a level holds more than kLeafMax triangles;
+                                               // leaves of a level take a slot too, hence not n / 5)
+    DBuf<float> d_pos, d_tb, d_cen;
+    DBuf<uint32_t> d_order, d_order2, d_nodeof, d_nodeof2, d_flag, d_rank, d_bins, d_word, d_inner, d_index;
+    DBuf<Node> d_nodes;
+    DBuf<BvhNode> d_out;
+    DBuf<char> d_temp;
+    int rc;
+    if ((rc = d_pos.ensure((size_t)n * 9)) || (rc = d_tb.ensure((size_t)n * 6)) || (rc = d_cen.ensure((size_t)n * 3)) || (rc = d_order.ensure(n)) ||
+        (rc = d_order2.ensure(n)) || (rc = d_nodeof.ensure(n)) || (rc = d_nodeof2.ensure(n)) || (rc = d_flag.ensure(n + 1)) || (rc = d_rank.ensure(n + 1)) ||
+        (rc = d_bins.ensure((size_t)bin_slots * kBinWords)) || (rc = d_word.ensure(2)) || (rc = d_inner.ensure(capacity)) ||
+        (rc = d_index.ensure(capacity)) || (rc = d_nodes.ensure(capacity)) || (rc = d_out.ensure(n)))
+        return rc;
+    size_t scan_bytes = 0, scan2_bytes = 0;
+    RRT_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_flag.p, d_rank.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), nullptr));
+    RRT_HIP(rocprim::exclusive_scan(nullptr, scan2_bytes, d_inner.p, d_index.p, 0u, (size_t)capacity, rocprim::plus<uint32_t>(), nullptr));
+    if ((rc = d_temp.ensure(std::max<size_t>(std::max(scan_bytes, scan2_bytes), 1)))) return rc;
+    lap("allocations");
+    RRT_HIP(hipMemcpy(d_pos.p, positions, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice));
+    Node root;
+    memset(&root, 0, sizeof(root));
+    root.lo = 0, root.hi = n, root.left = -2, root.axis = -1;
+    for (int k = 0; k < 3; k++) root.box[k] = root.cb[k] = 0xFFFFFFFFu, root.box[3 + k] = root.cb[3 + k] = 0u;
+    RRT_HIP(hipMemcpy(d_nodes.p, &root, sizeof(root), hipMemcpyHostToDevice));
+    RRT_HIP(hipMemset(d_word.p, 0, 2 * sizeof(uint32_t)));
+    RRT_HIP(hipMemset(d_flag.p + n, 0, sizeof(uint32_t)));  // the scan runs over n + 1 entries: rank[n] = all left-going triangles
+    lap("upload");
+    hipEvent_t e0, e1;
+    RRT_HIP(hipEventCreate(&e0));
+    RRT_HIP(hipEventCreate(&e1));
+    RRT_HIP(hipEventRecord(e0, nullptr));
+    const dim3 chunk_grid((uint32_t)(((uint64_t)n + kChunk * (kBlock / 64) - 1) / (kChunk * (kBlock / 64))));
+    hipLaunchKernelGGL(k_sah_prepare, chunk_grid, dim3(kBlock), 0, nullptr, d_pos.p, n, d_tb.p, d_cen.p, d_order.p, d_nodeof.p, d_nodes.p, d_word.p + 1);
+    uint32_t level_first = 0, level_count = 1, levels = 0, total = 1;
+    uint32_t *order_a = d_order.p, *order_b = d_order2.p, *nodeof_a = d_nodeof.p, *nodeof_b = d_nodeof2.p;
+    hipError_t se = hipGetLastError();
+    uint32_t word[2] = {0, 0};  // [0] nodes the level created, [1] error bits
+    while (se == hipSuccess) {
+        levels++;
+        if (level_count > bin_slots || levels > 4096) {  // a level wider than n / 2 nodes cannot be (see bin_slots)
+            word[1] |= 32u;
+            break;
+        }
+        hipLaunchKernelGGL(k_sah_clear_bins, grid_for((uint64_t)level_count * kBinWords), dim3(kBlock), 0, nullptr, d_bins.p, (uint64_t)level_count * kBinWords);
+        (void)hipMemsetAsync(d_word.p, 0, sizeof(uint32_t), nullptr);
+        hipLaunchKernelGGL(k_sah_bin, chunk_grid, dim3(kBlock), 0, nullptr, order_a, nodeof_a, d_nodes.p, d_tb.p, d_cen.p, n, level_first, d_bins.p);
+        hipLaunchKernelGGL(k_sah_decide, grid_for(level_count), dim3(kBlock), 0, nullptr, d_nodes.p, level_first, level_count, d_bins.p,
+                           level_first + level_count, capacity, d_word.p, d_word.p + 1);
+        if ((se = hipGetLastError()) != hipSuccess) break;
+        if ((se = hipMemcpy(word, d_word.p, sizeof(word), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if (word[1] || word[0] == 0) break;  // an error, or every node of this level is a leaf
+        hipLaunchKernelGGL(k_sah_flag, grid_for(n), dim3(kBlock), 0, nullptr, order_a, nodeof_a, d_nodes.p, d_cen.p, n, d_flag.p);
+        se = rocprim::exclusive_scan(d_temp.p, scan_bytes, d_flag.p, d_rank.p, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), nullptr);
+        if (se != hipSuccess) break;
+        const ScatterArgs sa = {order_a, nodeof_a, d_nodes.p, d_tb.p, d_cen.p, d_flag.p, d_rank.p, order_b, nodeof_b};
+        hipLaunchKernelGGL(k_sah_scatter, chunk_grid, dim3(kBlock), 0, nullptr, sa, n);
+        std::swap(order_a, order_b);
+        std::swap(nodeof_a, nodeof_b);
+        level_first += level_count;
+        level_count = word[0];
+        total += word[0];
+        se = hipGetLastError();
+    }
+    uint32_t n_inner = 0;
+    if (se == hipSuccess && word[1] == 0) {
+        hipLaunchKernelGGL(k_sah_mark_inner, grid_for(total), dim3(kBlock), 0, nullptr, d_nodes.p, total, d_inner.p);
+        se = rocprim::exclusive_scan(d_temp.p, scan2_bytes, d_inner.p, d_index.p, 0u, (size_t)total, rocprim::plus<uint32_t>(), nullptr);
+        if (se == hipSuccess) {
+            hipLaunchKernelGGL(k_sah_emit, grid_for(total), dim3(kBlock), 0, nullptr, d_nodes.p, total, d_inner.p, d_index.p, n, d_out.p, d_word.p + 1);
+            se = hipGetLastError();
+        }
+        uint32_t last[2] = {0, 0};
+        if (se == hipSuccess) se = hipMemcpy(&last[0], d_index.p + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (se == hipSuccess) se = hipMemcpy(&last[1], d_inner.p + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (se == hipSuccess) se = hipMemcpy(word, d_word.p, sizeof(word), hipMemcpyDeviceToHost);
+        n_inner = last[0] + last[1];
+    }
+    hipError_t re = hipEventRecord(e1, nullptr);
+    hipError_t ye = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (se == hipSuccess && re == hipSuccess && ye == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    RRT_HIP(se);
+    RRT_HIP(re);
+    RRT_HIP(ye);
+    if (device_ms) *device_ms = ms;
+    lap("kernels (wall)");
+    if (timing) fprintf(stderr, "[sah] kernels (HIP events)         %8.2f ms, %u levels, %u nodes\n", ms, levels, total);
+    if (word[1] == 1u) return 1;  // non-finite input: the host builder's business
+    if (word[1] || n_inner == 0 || n_inner >= n || total > capacity) {
+        char what[160];
+        snprintf(what, sizeof(what), "device SAH build produced an invalid tree (internal error): check bits 0x%x, %u inner nodes of %u, %u levels", word[1],
+                 n_inner, total, levels);
+        return fail(RRT_ERR_DEVICE, what);
+    }
+    nodes.resize(n_inner);
+    order.resize(n);
+    RRT_HIP(hipMemcpy(nodes.data(), d_out.p, (size_t)n_inner * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    RRT_HIP(hipMemcpy(order.data(), order_a, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    max_depth = levels;
+    lap("download");
+    return RRT_OK;
+}
+
+}  // namespace rrt

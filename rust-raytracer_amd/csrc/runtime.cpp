@@ -251,13 +251,21 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
             std::vector<BvhNode> nodes;
             uint32_t depth = 0;
             auto t0 = std::chrono::steady_clock::now();
+            bool built = false;
+            int rc = RRT_OK;
             if (F.bvh_builder == RRT_BVH_DEVICE_LBVH && n > 4) {
-                int rc = build_bvh_device(o.tri_pos.data(), n, order, nodes, depth, nullptr);
-                if (rc) {
-                    if (!F.error) F.error = rc;
-                    break;
-                }
-            } else {
+                rc = build_bvh_device(o.tri_pos.data(), n, order, nodes, depth, nullptr);
+                built = true;
+            } else if (F.bvh_builder == RRT_BVH_DEVICE_SAH && n > 4) {
+                rc = build_bvh_device_sah(o.tri_pos.data(), n, order, nodes, depth, nullptr);
+                built = rc != 1;  // 1: a coordinate is not finite: the host builder and its "wild mesh" rules take the mesh
+                if (!built) rc = RRT_OK;
+            }
+            if (rc) {
+                if (!F.error) F.error = rc;
+                break;
+            }
+            if (!built) {
                 build_bvh(o.tri_pos.data(), n, order, nodes, depth);
             }
             F.ms_bvh_build += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -386,7 +394,7 @@ int flatten_materials(rrt_scene *s, std::vector<DevMaterial> &out, bool &reflect
 int flatten_scene(rrt_scene *s) {
     drop_render_workers(s);  // they point into the device arrays replaced below
     Flat F;
-    if (s->params.bvh_builder > RRT_BVH_DEVICE_LBVH) return fail(RRT_ERR_INVALID, "unknown bvh_builder");
+    if (s->params.bvh_builder > RRT_BVH_DEVICE_SAH) return fail(RRT_ERR_INVALID, "unknown bvh_builder");
     F.bvh_builder = s->params.bvh_builder;
     g_bounds_enabled = getenv("RRT_NO_BOUNDS") == nullptr;  // debugging aid: the reference's plain all-objects loop
     uint32_t max_stack = 0;

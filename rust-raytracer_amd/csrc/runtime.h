@@ -195,6 +195,9 @@ void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<B
 // bvh_lbvh.hip: the same outputs from the device-side LBVH build (n > 4); device_ms = HIP-event time of its kernels
 int build_bvh_device(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
                      float *device_ms);
+// bvh_sah.hip: the host builder's tree, built on the device.  Returns 1 (not an rrt error) when a coordinate is not finite.
+int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
+                     float *device_ms);
 void drop_render_workers(rrt_scene *s);
 // HIP's current device is per thread (new threads start on device 0): entry points that touch the scene's memory call this
 int use_scene_device(const rrt_scene *s);  // before device data of the scene or its photon maps is rebuilt

@@ -269,7 +269,7 @@ def load_teapot(repo, name="teapot.obj"):
     return test_host_side.python_obj_loader(os.path.join(repo, "assets/models", name))
 
 
-BUILDERS = [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH]
+BUILDERS = [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH, abi.BVH_DEVICE_SAH]
 
 
 @pytest.mark.parametrize("builder", BUILDERS)
@@ -300,8 +300,8 @@ def test_device_lbvh_degenerate_meshes_and_errors():
     tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
     grid = np.array([[[x, y, 0], [x + 1, y, 0], [x, y + 1, 0]] for y in range(20) for x in range(20)], np.float32)
     cases = [np.repeat(tri[None], 37, 0), grid] + [grid[:n] for n in (5, 6, 9, 17)]
-    for pos in cases:
-        cpu, gpu = mesh_pair(pos, None, False, abi.BVH_DEVICE_LBVH)
+    for pos, builder in [(p, b) for p in cases for b in (abi.BVH_DEVICE_LBVH, abi.BVH_DEVICE_SAH)]:
+        cpu, gpu = mesh_pair(pos, None, False, builder)
         rng = np.random.default_rng(len(pos))
         hi = pos.reshape(-1, 3)[:, :2].max(0)
         # from above: the triangles face +z, and only entering hits are visible (environment.rs:39-44)
@@ -319,6 +319,49 @@ def test_device_lbvh_degenerate_meshes_and_errors():
     assert e.value.code == abi.ERR_INVALID
 
 
+def _flattened_arrays(make_scene, builder, path):
+    """The flattened scene as RRT_DUMP_SCENE writes it (debugging aid of the flattener: element size, count, bytes per array)."""
+    import struct
+
+    os.environ["RRT_DUMP_SCENE"] = path
+    try:
+        s = make_scene(rrt.Scene(params=rrt.default_params(bvh_builder=builder)))
+        s.pre_render(1)
+    finally:
+        del os.environ["RRT_DUMP_SCENE"]
+    b, off, out = open(path, "rb").read(), 0, []
+    while off < len(b):
+        e, n = struct.unpack_from("<QQ", b, off)
+        out.append(b[off + 16:off + 16 + e * n])
+        off += 16 + e * n
+    return out, s.stats()["ms_bvh_build"]
+
+
+def test_device_sah_builds_the_host_builders_tree(repo, tmp_path):
+    """RRT_BVH_DEVICE_SAH runs bvh_build.cpp's algorithm level by level on the GPU with the same f32 operations: the
+    flattened scene (triangle order, quantised four-wide nodes, grid, stack need) is the host builder's, byte for byte —
+    on the teapot and on a soup with duplicates and degenerate triangles.  (Where every centroid of a node coincides both
+    builders split by position, and positions depend on the host's unstable std::partition: such meshes get an equally valid
+    tree with another triangle order; test_device_lbvh_degenerate_meshes_and_errors traces them.)  A mesh with a non-finite
+    coordinate goes to the host builder (its 'wild mesh' rules)."""
+    pos_t, nrm_t = load_teapot(repo)
+    rng = np.random.default_rng(11)
+    n = 40000
+    centre = (rng.random((n, 1, 3)) - 0.5) * 20
+    soup = (centre + (rng.random((n, 3, 3)) - 0.5) * rng.choice([0.05, 0.5, 3.0], (n, 1, 1))).astype(np.float32)
+    soup[:50] = soup[50:100]
+    soup[100:110, 2] = soup[100:110, 1]
+    wild = soup[:300].copy()
+    wild[7, 1, 2] = np.inf
+    for name, pos, nrm in (("teapot", pos_t, nrm_t), ("soup", soup, None), ("wild", wild, None)):
+        make = lambda s: (s.add_object(kit.mesh(s, pos, nrm, kit.falsecolour(s), nrm is not None)), s)[1]
+        host, _ = _flattened_arrays(make, abi.BVH_HOST_SAH, str(tmp_path / "host.bin"))
+        dev, ms = _flattened_arrays(make, abi.BVH_DEVICE_SAH, str(tmp_path / "dev.bin"))
+        assert len(host) == len(dev) and ms > 0
+        for k, (a, b) in enumerate(zip(host, dev)):
+            assert a == b, (name, "array", k, len(a), len(b))
+
+
 def test_device_lbvh_frames_equal_host_sah_frames(repo):
     """Whole frames (mesh + plane + light, shadows, FalseColour and Phong) are bit-identical whichever builder made the tree."""
     frames = []
@@ -328,8 +371,9 @@ def test_device_lbvh_frames_equal_host_sah_frames(repo):
         gpu.pre_render(1)
         cam.width, cam.height = 320, 240
         frames.append(gpu.render(cam))
-    for a, b in zip(*frames):
-        assert np.array_equal(bits(a), bits(b))
+    for other in frames[1:]:
+        for a, b in zip(frames[0], other):
+            assert np.array_equal(bits(a), bits(b))
 
 
 def test_bvh_tiny_meshes():

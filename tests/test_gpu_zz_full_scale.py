@@ -52,14 +52,15 @@ def test_c4_million_triangle_mesh_4k_both_builders_and_oracle_sample(repo):
 
     frames = []
     scenes = []
-    for builder in (abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH):
+    for builder in (abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH, abi.BVH_DEVICE_SAH):
         s = build(rrt.Scene(params=rrt.default_params(bvh_builder=builder)))
         s.pre_render(1)
         frames.append(s.render(cam))
         scenes.append(s)
     bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
-    for a, b in zip(*frames):
-        assert np.array_equal(bits(a), bits(b))
+    for other in frames[1:]:
+        for a, b in zip(frames[0], other):
+            assert np.array_equal(bits(a), bits(b))
     rgb, depth, ids = frames[0]
     assert (ids == 0).mean() > 0.1 and (ids == 1).mean() > 0.05          # teapots and floor both in view
     top, bottom = scenes[1].render(cam, 0, 1000), scenes[1].render(cam, 1000, 2160)
