@@ -54,7 +54,7 @@ def teapot_grid(nx=13, nz=13, spacing=34.0):
     return np.ascontiguousarray(np.concatenate(P), np.float32), np.ascontiguousarray(np.concatenate(N), np.float32)
 
 
-def build_mesh_scene(rrt, smooth=True, bvh_builder=0, variant="phong", scene=None):
+def build_mesh_scene(rrt, smooth=True, bvh_builder=3, variant="phong", scene=None):
     """variant: "phong" (BASELINE configs[3]: Monochrome teapots, primary + shadow rays), "nolight" (the same without the
     light: primary rays only), "mirror" (teapots `Simple` = Compound[Monochrome, Global(reflect 0.6)], floor mirror too:
     reflection rays bounce between the teapots and the floor, compound_material.rs:39-49) and "glass" (`Transparent`,
@@ -114,7 +114,7 @@ def build_mesh_scene(rrt, smooth=True, bvh_builder=0, variant="phong", scene=Non
     return s, cam, pos.shape[0]
 
 
-def run_mesh(rrt, torch, steps=5, bvh_builder=0):
+def run_mesh(rrt, torch, steps=5, bvh_builder=3):
     t0 = time.perf_counter()
     scene, cam, ntri = build_mesh_scene(rrt, bvh_builder=bvh_builder)
     t_build_host = time.perf_counter() - t0
@@ -151,7 +151,7 @@ def run_mesh(rrt, torch, steps=5, bvh_builder=0):
         "hit_fraction": float((ids >= 0).float().mean().item()),
         "bvh_nodes_per_ray": st["bvh_nodes_visited"] / (st["rays_primary"] + st["rays_shadow"]),
         "bvh_tris_per_ray": st["bvh_tris_tested"] / (st["rays_primary"] + st["rays_shadow"]),
-        "bvh_builder": ("host binned SAH", "device LBVH", "device binned SAH")[bvh_builder],
+        "bvh_builder": ("host binned SAH", "device LBVH", "device binned SAH", "auto: binned SAH, on the device for a mesh of this size")[bvh_builder],
         "ms_bvh_build": st["ms_bvh_build"],
         "host_seconds": {"mesh_generation": t_build_host, "pre_render_incl_bvh_build": t_pre},
         "roofline": {"kernel": "k_trace_shade", "bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
@@ -330,8 +330,8 @@ if __name__ == "__main__":
         res["mesh_1m"] = run_mesh(rrt, torch)
     if which in ("all", "mesh_lbvh"):
         res["mesh_1m_device_lbvh"] = run_mesh(rrt, torch, bvh_builder=1)
-    if which in ("all", "mesh_dsah"):
-        res["mesh_1m_device_sah"] = run_mesh(rrt, torch, bvh_builder=2)
+    if which in ("all", "mesh_hsah"):
+        res["mesh_1m_host_sah"] = run_mesh(rrt, torch, bvh_builder=0)
     if which in ("all", "photon"):
         res["photon_1m"] = run_photon(rrt, torch)
     if which in ("all", "csg"):

@@ -57,7 +57,9 @@ typedef struct rrt_params {
                                            the caller's stream only, the default; at most 8).  Measured
                                            on MI355X: 2 / 4 / 8 streams are 9 / 21 / 100 % slower on the
                                            1080p CSG scene, so this is off by default      */
-    uint32_t bvh_builder;               /* RRT_BVH_HOST_SAH (0, default): binned-SAH build on the host, the faster trees;
+    uint32_t bvh_builder;               /* RRT_BVH_AUTO (3, what rrt_params_default sets): RRT_BVH_DEVICE_SAH for meshes of
+                                           32768 triangles or more, RRT_BVH_HOST_SAH below (same tree either way);
+                                           RRT_BVH_HOST_SAH (0): binned-SAH build on the host, the faster trees;
                                            RRT_BVH_DEVICE_LBVH (1): Morton-order build on the GPU for meshes of more
                                            than 4 triangles (rebuilds in milliseconds; same frames, slower traversal);
                                            RRT_BVH_DEVICE_SAH (2): the host builder's algorithm level by level on the GPU:
@@ -77,7 +79,7 @@ typedef struct rrt_params {
     uint32_t reserved[5];
 } rrt_params;
 #define RRT_GATHER_K_MAX 4096
-enum rrt_bvh_builder { RRT_BVH_HOST_SAH = 0, RRT_BVH_DEVICE_LBVH = 1, RRT_BVH_DEVICE_SAH = 2 };
+enum rrt_bvh_builder { RRT_BVH_HOST_SAH = 0, RRT_BVH_DEVICE_LBVH = 1, RRT_BVH_DEVICE_SAH = 2, RRT_BVH_AUTO = 3 };
 
 /* ---- materials (src/materials) ------------------------------------------------------ */
 enum rrt_material_kind {

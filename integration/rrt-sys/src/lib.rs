@@ -29,6 +29,7 @@ pub const RRT_MODE_PHOTON: c_int = 1;
 pub const RRT_BVH_HOST_SAH: u32 = 0;
 pub const RRT_BVH_DEVICE_LBVH: u32 = 1;
 pub const RRT_BVH_DEVICE_SAH: u32 = 2;
+pub const RRT_BVH_AUTO: u32 = 3;
 
 pub const RRT_GATHER_K_MAX: u32 = 4096;
 pub const RRT_NOALLOC_MAX_RAYS: usize = 65536;

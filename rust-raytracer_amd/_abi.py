@@ -13,7 +13,7 @@ NOALLOC_MAX_RAYS = 65536  # RRT_NOALLOC_MAX_RAYS
 GATHER_K_MAX = 4096  # RRT_GATHER_K_MAX
 
 
-BVH_HOST_SAH, BVH_DEVICE_LBVH, BVH_DEVICE_SAH = 0, 1, 2
+BVH_HOST_SAH, BVH_DEVICE_LBVH, BVH_DEVICE_SAH, BVH_AUTO = 0, 1, 2, 3
 
 
 class Params(C.Structure):

@@ -136,6 +136,7 @@ void rrt_params_default(rrt_params *p) {
     p->max_photon_bounces = 64;
     p->max_vueon_depth = 12;
     p->chunk_pixels = 0;
+    p->bvh_builder = RRT_BVH_AUTO;
 }
 
 // full_camera.rs:23-58

@@ -91,6 +91,7 @@ struct Flat {
     uint32_t bvh_depth = 0;
     uint64_t flops = 0;
     uint32_t bvh_builder = RRT_BVH_HOST_SAH;
+    bool have_device = false;  // RRT_BVH_AUTO builds large meshes on the device only where there is one (flattening for tools/cpu_emu needs none)
     int error = RRT_OK;       // first failure inside emit (device BVH build)
     double ms_bvh_build = 0;  // host wall clock
 };
@@ -256,7 +257,7 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
             if (F.bvh_builder == RRT_BVH_DEVICE_LBVH && n > 4) {
                 rc = build_bvh_device(o.tri_pos.data(), n, order, nodes, depth, nullptr);
                 built = true;
-            } else if (F.bvh_builder == RRT_BVH_DEVICE_SAH && n > 4) {
+            } else if ((F.bvh_builder == RRT_BVH_DEVICE_SAH && n > 4) || (F.bvh_builder == RRT_BVH_AUTO && n >= 32768 && F.have_device)) {
                 rc = build_bvh_device_sah(o.tri_pos.data(), n, order, nodes, depth, nullptr);
                 built = rc != 1;  // 1: a coordinate is not finite: the host builder and its "wild mesh" rules take the mesh
                 if (!built) rc = RRT_OK;
@@ -394,8 +395,12 @@ int flatten_materials(rrt_scene *s, std::vector<DevMaterial> &out, bool &reflect
 int flatten_scene(rrt_scene *s) {
     drop_render_workers(s);  // they point into the device arrays replaced below
     Flat F;
-    if (s->params.bvh_builder > RRT_BVH_DEVICE_SAH) return fail(RRT_ERR_INVALID, "unknown bvh_builder");
+    if (s->params.bvh_builder > RRT_BVH_AUTO) return fail(RRT_ERR_INVALID, "unknown bvh_builder");
     F.bvh_builder = s->params.bvh_builder;
+    {
+        int ndev_probe = 0;
+        F.have_device = hipGetDeviceCount(&ndev_probe) == hipSuccess && ndev_probe > 0;
+    }
     g_bounds_enabled = getenv("RRT_NO_BOUNDS") == nullptr;  // debugging aid: the reference's plain all-objects loop
     uint32_t max_stack = 0;
     bool has_csg = false, has_bounds = false, csg_mesh = false;
