@@ -1,6 +1,6 @@
 // bvh_lbvh.hip — device-side LBVH build: steps 1-8 of bvh_lbvh.h as kernels (build, validation, depth, compaction).
-// Selected with rrt_params.bvh_builder = RRT_BVH_DEVICE_LBVH; the default stays the host's binned-SAH builder, whose
-// trees traverse faster.  This one is for scenes that are rebuilt often (the reference's watch loop, main.rs:86-99).
+// Selected with rrt_params.bvh_builder = RRT_BVH_DEVICE_LBVH; the default is the binned-SAH tree (bvh_build.cpp on the
+// host, bvh_sah.hip on the device), which traverses faster.  This one is for scenes that are rebuilt often (the reference's watch loop, main.rs:86-99).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

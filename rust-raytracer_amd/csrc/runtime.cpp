@@ -260,6 +260,9 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
             } else if ((F.bvh_builder == RRT_BVH_DEVICE_SAH && n > 4) || (F.bvh_builder == RRT_BVH_AUTO && n >= 32768 && F.have_device)) {
                 rc = build_bvh_device_sah(o.tri_pos.data(), n, order, nodes, depth, nullptr);
                 built = rc != 1;  // 1: a coordinate is not finite: the host builder and its "wild mesh" rules take the mesh
+                // RRT_BVH_AUTO promises a tree, not a device build: whatever the device builder refuses (its workspace does not
+                // fit, a tree deeper than its level limit) goes to the host builder, which makes the same tree
+                if (rc < 0 && F.bvh_builder == RRT_BVH_AUTO) built = false;
                 if (!built) rc = RRT_OK;
             }
             if (rc) {
