@@ -82,6 +82,8 @@ struct TraceArgs {
     uint32_t band_rows;   // rows of the band being rendered (camera renders)
     uint32_t lds_slots;   // hit-list slots per lane (0 = scene has no CSG)
     uint32_t fuse;        // 1: raytracing mode and level 0 is the whole recursion: k_trace_shade writes the frame itself
+    uint32_t tile_order;  // 1: level 0 takes the frame's 8x8 tiles in the XCD-interleaved supertile order (node_pixel); set
+                          // where the trace launches are one-wave blocks, i.e. everywhere but raytraced scenes with CSG
     float gather_half_width;
     uint32_t *next_count;
     uint32_t *err;

@@ -662,6 +662,7 @@ void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, ui
     A.band_rows = cam && cam->width ? n_pixels / cam->width : 0;
     A.lds_slots = D.lds_slots;
     A.fuse = (s->mode == RRT_MODE_SCENE && !D.reflective) ? 1u : 0u;  // single-level frames need no combine pass
+    A.tile_order = (s->mode == RRT_MODE_SCENE && D.view.has_csg) ? 0u : 1u;  // as launch_trace_shade picks the block size
     A.gather_half_width = s->params.gather_half_width;
     A.err = L.ctr + 63;
     A.stats = s->stats_dev.p;
