@@ -376,14 +376,9 @@ void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<B
     struct Work {
         uint32_t src, dst;
     };
-    std::vector<Work> work;
-    std::vector<uint32_t> parent_need;  // per output node: stack entries in use when the traversal arrives at it, at most
-    out.emplace_back();
-    parent_need.push_back(0);
-    work.push_back({0u, 0u});
-    while (!work.empty()) {
-        const Work w = work.back();
-        work.pop_back();
+    // One output node: the slots of BVH2 node w.src go to outv[w.dst]; inner children get their output index (the next
+    // free one of outv) and a work item.  needv: per output node, stack entries in use when the traversal arrives at it.
+    auto expand = [&](const Work w, std::vector<BvhNodeQ> &outv, std::vector<uint32_t> &needv, std::vector<Work> &workv, uint32_t &need_max) {
         Slot sl[4];
         int m = 0;
         for (int c = 0; c < 2; c++)
@@ -414,21 +409,85 @@ void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<B
             o.child[k] = RRT_BVH_EMPTY;
         }
         // stack entries while below this node: what was there on arrival + its other children
-        const uint32_t below = parent_need[w.dst] + (m > 0 ? (uint32_t)m - 1u : 0u);
-        stack_need = std::max(stack_need, below);
+        const uint32_t below = needv[w.dst] + (m > 0 ? (uint32_t)m - 1u : 0u);
+        need_max = std::max(need_max, below);
         for (int k = 0; k < m; k++) {
             for (int a = 0; a < 3; a++) o.q[4 * a + k] = q_down(sl[k].lo[a], a) | (q_up(sl[k].hi[a], a) << 16);
             if (sl[k].ref >= 0) {
-                const uint32_t dst = (uint32_t)out.size();
-                out.emplace_back();
-                parent_need.push_back(below);
-                work.push_back({(uint32_t)sl[k].ref, dst});
+                const uint32_t dst = (uint32_t)outv.size();
+                outv.emplace_back();
+                needv.push_back(below);
+                workv.push_back({(uint32_t)sl[k].ref, dst});
                 o.child[k] = (int32_t)dst;
             } else {
                 o.child[k] = -(int32_t)((((uint32_t)(~sl[k].ref)) << 4) | (sl[k].cnt & 15u)) - 1;
             }
         }
-        out[w.dst] = o;
+        outv[w.dst] = o;
+    };
+    std::vector<Work> work;
+    std::vector<uint32_t> parent_need;
+    out.emplace_back();
+    parent_need.push_back(0);
+    work.push_back({0u, 0u});
+    // Large trees: the top of the tree breadth first until there are a few hundred pending subtrees, then each subtree depth
+    // first in a node pool of its own on up to 16 host threads, spliced in job order (the result does not depend on the
+    // number of threads: the jobs and their order are fixed by the tree).  Small trees: depth first, serially.
+    const bool threaded = nodes.size() >= 32768;
+    std::vector<Work> jobs;
+    if (threaded) {
+        size_t head = 0;
+        while (head < work.size() && work.size() - head < 512) expand(work[head++], out, parent_need, work, stack_need);
+        jobs.assign(work.begin() + head, work.end());
+        work.clear();
+    }
+    while (!work.empty()) {
+        const Work w = work.back();
+        work.pop_back();
+        expand(w, out, parent_need, work, stack_need);
+    }
+    if (!jobs.empty()) {
+        struct Pool {
+            std::vector<BvhNodeQ> out;
+            std::vector<uint32_t> need;
+            uint32_t need_max = 0;
+        };
+        std::vector<Pool> pools(jobs.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                const size_t j = next.fetch_add(1);
+                if (j >= jobs.size()) return;
+                Pool &P = pools[j];
+                P.out.emplace_back();                         // local index 0 = the job's root (out[jobs[j].dst])
+                P.need.push_back(parent_need[jobs[j].dst]);
+                std::vector<Work> st;
+                st.push_back({jobs[j].src, 0u});
+                while (!st.empty()) {
+                    const Work w = st.back();
+                    st.pop_back();
+                    expand(w, P.out, P.need, st, P.need_max);
+                }
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_threads = std::min<size_t>(std::min<size_t>(hw ? hw : 4, 16), jobs.size());
+        std::vector<std::thread> threads;
+        for (size_t t = 1; t < n_threads; t++) threads.emplace_back(worker);
+        worker();
+        for (auto &t : threads) t.join();
+        for (size_t j = 0; j < jobs.size(); j++) {  // local index i > 0 becomes base + i - 1
+            const Pool &P = pools[j];
+            const int32_t base = (int32_t)out.size();
+            auto fix = [&](BvhNodeQ o) {
+                for (int k = 0; k < 4; k++)
+                    if (o.child[k] >= 0) o.child[k] += base - 1;
+                return o;
+            };
+            out[jobs[j].dst] = fix(P.out[0]);
+            for (size_t i = 1; i < P.out.size(); i++) out.push_back(fix(P.out[i]));
+            stack_need = std::max(stack_need, P.need_max);
+        }
     }
     stack_need += 1;  // the count above is of entries below the current node; one word of slack
 }
