@@ -6,14 +6,15 @@
 //
 // One level of the tree per round, all of its nodes at once:
 //   bin      every triangle of a node with more than kLeafMax triangles grows the bin of its centroid on each axis
-//            (atomics on order-preserving words; a wave whose 1024 positions lie in ONE node collects them in LDS first)
+//            (atomics on order-preserving words; runs of 64 or more positions of one node are collected in LDS first)
 //   decide   one thread per node: sweep the 3 x 15 candidate planes as the host does, create the two children
 //   flag     which side each triangle goes to; exclusive scan of the flags (rocPRIM)
 //   scatter  stable partition of every node's range at once (position = range start + rank on its side), the children's
 //            centroid bounds collected on the way
-// The host reads one word per level (how many nodes the level created) and stops when it is zero.
+// The host reads one word per level (how many nodes the level created) and stops when it is zero.  Nodes of at most 64
+// triangles leave the rounds early: k_sah_small finishes each such subtree with one wave, bins and partition in LDS.
 //
-// Memory is spent freely (MI355X: 288 GB): 2n node records, one 1344-byte bin block per node of the widest level.
+// Memory is spent freely (MI355X: 288 GB): 4n node records, one 1344-byte bin block per node of the widest level.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,7 +48,11 @@ struct Node {
     int32_t axis, split;  // axis < 0: no plane found (all centroids coincide), split by position at lo + n_left
     uint32_t box[6];      // ordered words: lo xyz, hi xyz of the triangles' boxes
     uint32_t cb[6];       // same for their centroids
+    uint32_t depth;       // root = 1 (bvh_build.cpp's Work::depth)
+    uint32_t pad;
 };
+constexpr uint32_t kSmall = 64;  // a node of at most this many triangles leaves the level rounds: k_sah_small finishes its subtree, one wave, in LDS
+constexpr int32_t kPendingSmall = -3;
 
 // empty-aware decode: 0xFFFFFFFF / 0 are the "nothing seen" values of a lower / upper word
 __device__ __forceinline__ float dec_lo(uint32_t u) { return u == 0xFFFFFFFFu ? __builtin_huge_valf() : unordered(u); }
@@ -116,7 +121,7 @@ __device__ __forceinline__ int bin_of(float c, float lo, float scale) {
 // kLongRun or more is collected in the wave's LDS bins first and only the bins it touched go to memory (a top-level node
 // would otherwise put 21 atomics per triangle on the same eleven cache lines); shorter runs use the atomics directly.
 constexpr uint32_t kLongRun = 64;
-__device__ __forceinline__ bool splits(const Node &N) { return N.left == -2 && N.hi - N.lo > kLeafMax; }
+__device__ __forceinline__ bool splits(const Node &N) { return N.left == -2 && N.hi - N.lo > kSmall; }
 __device__ __forceinline__ void bin_triangle(uint32_t *bins_of_node, const Node &N, const float *tb, const float *cen, uint32_t t) {
     uint32_t bw[6];
     for (int k = 0; k < 6; k++) bw[k] = ordered(tb[(size_t)t * 6 + k]);
@@ -213,6 +218,10 @@ __global__ __launch_bounds__(kBlock) void k_sah_decide(Node *nodes, uint32_t lev
         N.left = -1;
         return;
     }
+    if (cnt <= kSmall) {
+        N.left = kPendingSmall;
+        return;
+    }
     const uint32_t *B = bins + (size_t)k * kBinWords;
     int best_axis = -1, best_split = -1;
     float best_cost = __builtin_huge_valf();
@@ -271,6 +280,8 @@ __global__ __launch_bounds__(kBlock) void k_sah_decide(Node *nodes, uint32_t lev
     }
     L.lo = N.lo, L.hi = R.lo = N.lo + n_left, R.hi = N.hi;
     L.left = R.left = -2;
+    L.depth = R.depth = N.depth + 1u;
+    L.pad = R.pad = 0u;
     L.n_left = R.n_left = 0;
     L.axis = R.axis = -1, L.split = R.split = 0;
     N.left = (int32_t)(next_first + pair);
@@ -390,6 +401,207 @@ __global__ __launch_bounds__(kBlock) void k_sah_scatter(ScatterArgs A, uint32_t 
     }
 }
 
+// 4b. The subtree of a node of at most kSmall triangles, by one wave: lane l holds the triangle at position lo + l of the
+// node at hand (box, centroid, index in registers), bins live in LDS, the candidate planes are swept by 45 lanes at once,
+// and a split is a stable partition of the lanes (ballots for the ranks, one trip through LDS for the registers).  Same
+// bins, costs and tie rule as k_sah_decide and bvh_build.cpp.  Replaces the deepest ten or so level rounds, which paid
+// 21 global atomics per triangle and round.
+struct SmallLds {
+    uint32_t bins[kBinWords];
+    uint32_t move[10][64];
+    uint32_t stack[kSmall][4];  // node, first lane, end lane, depth
+};
+__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+#define SAH_LDS_SYNC()                                      \
+    do {                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                    \
+    } while (0)
+__global__ __launch_bounds__(kBlock) void k_sah_small(Node *nodes, uint32_t total, uint32_t capacity, uint32_t *order, const float *tb, const float *cen,
+                                                      uint32_t *alloc, uint32_t *max_depth, uint32_t *err) {
+    __shared__ SmallLds s_lds[kBlock / 64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t root = blockIdx.x * (kBlock / 64) + wave;
+    if (root >= total) return;  // whole waves leave; no block-wide barrier anywhere below
+    if (nodes[root].left != kPendingSmall) return;
+    SmallLds &S = s_lds[wave];
+    const uint32_t lo = nodes[root].lo, cnt = nodes[root].hi - lo;
+    if (cnt > kSmall || cnt <= kLeafMax) {  // cannot be: k_sah_decide marks exactly these
+        if (lane == 0) atomicOr(err, 64u);
+        return;
+    }
+    // this lane's triangle (lanes >= cnt hold nothing and never take part)
+    uint32_t t = 0, bw[6] = {0, 0, 0, 0, 0, 0};
+    float ce[3] = {0.0f, 0.0f, 0.0f};
+    if (lane < cnt) {
+        t = order[lo + lane];
+        for (int k = 0; k < 6; k++) bw[k] = ordered(tb[(size_t)t * 6 + k]);
+        for (int a = 0; a < 3; a++) ce[a] = cen[(size_t)t * 3 + a];
+    }
+    // the subtree's node records: one allocation of the most it can need (a binary tree over cnt leaves: 2 cnt - 2 nodes below
+    // its root), handed out from a wave-local count; what is left over is marked unused at the end.  (One atomic per wave:
+    // an atomic per split, 400 k of them on one word, serialise in the L2 and took 3 of this kernel's 3.7 ms.)
+    const uint32_t block_nodes = 2u * cnt - 2u;
+    uint32_t first_node = 0, used = 0;
+    if (lane == 0) first_node = atomicAdd(alloc, block_nodes);
+    first_node = total + (uint32_t)__shfl((int)first_node, 0, 64);
+    if (first_node + block_nodes > capacity) {
+        if (lane == 0) atomicOr(err, 2u);
+        return;
+    }
+    uint32_t sp = 0, deepest = 0;
+    if (lane == 0) S.stack[0][0] = root, S.stack[0][1] = 0u, S.stack[0][2] = cnt, S.stack[0][3] = nodes[root].depth;
+    sp = 1;
+    SAH_LDS_SYNC();
+    while (sp) {  // wave-uniform
+        sp--;
+        const uint32_t node = S.stack[sp][0], a = S.stack[sp][1], b = S.stack[sp][2], dep = S.stack[sp][3];
+        SAH_LDS_SYNC();
+        const uint32_t c = b - a;
+        deepest = max(deepest, dep);
+        if (c <= kLeafMax) {
+            if (lane == 0) nodes[node].left = -1;
+            continue;
+        }
+        const bool in = lane >= a && lane < b;
+        // centroid bounds of the node (bvh_build.cpp:102-104)
+        float clo[3], ext[3];
+        for (int x = 0; x < 3; x++) {
+            const uint32_t o = ordered(ce[x]);
+            const float l = unordered(wave_min_u(in ? o : 0xFFFFFFFFu)), h = unordered(wave_max_u(in ? o : 0u));
+            clo[x] = l;
+            ext[x] = h - l;
+        }
+        for (uint32_t k = lane; k < kBinWords; k += 64) S.bins[k] = (k % 7) < 3 ? 0xFFFFFFFFu : 0u;
+        SAH_LDS_SYNC();
+        int my_bin[3] = {0, 0, 0};
+        if (in) {
+            for (int x = 0; x < 3; x++) {
+                if (!(ext[x] > 0.0f)) continue;
+                my_bin[x] = bin_of(ce[x], clo[x], (float)kBins / ext[x]);
+                uint32_t *d = S.bins + (x * kBins + my_bin[x]) * 7;
+                for (int k = 0; k < 3; k++) atomicMin(d + k, bw[k]);
+                for (int k = 3; k < 6; k++) atomicMax(d + k, bw[k]);
+                atomicAdd(d + 6, 1u);
+            }
+        }
+        SAH_LDS_SYNC();
+        // candidate plane (axis x, after bin s) on lane x * 15 + s: the host's sweep, both sides accumulated afresh
+        float cost = __builtin_huge_valf();
+        if (lane < 45) {
+            const int x = (int)lane / 15, sb = (int)lane % 15;
+            if (ext[x] > 0.0f) {
+                const uint32_t *A = S.bins + x * kBins * 7;
+                FBox L, R;
+                L.reset();
+                R.reset();
+                uint32_t cl = 0, cr = 0;
+                for (int q = 0; q < kBins; q++) {
+                    const FBox B = load_bin(A + q * 7);
+                    if (q <= sb)
+                        L.grow(B), cl += A[q * 7 + 6];
+                    else
+                        R.grow(B), cr += A[q * 7 + 6];
+                }
+                if (cl != 0 && cr != 0) {
+                    const float v = L.half_area() * (float)cl + R.half_area() * (float)cr;
+                    if (v < __builtin_huge_valf()) cost = v;  // as `cost < best_cost` from +inf: NaN and +inf never win
+                }
+            }
+        }
+        // the first strictly lowest cost in (axis, bin) order = the lowest lane among the minima
+        float best = cost;
+        uint32_t who = lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const uint32_t ow = (uint32_t)__shfl_xor((int)who, off, 64);
+            if (ob < best || (ob == best && ow < who)) best = ob, who = ow;
+        }
+        const bool by_plane = best < __builtin_huge_valf();
+        const int axis = by_plane ? (int)who / 15 : -1, split = by_plane ? (int)who % 15 : 0;
+        bool left = false;
+        if (in) left = by_plane ? (axis == 0 ? my_bin[0] : (axis == 1 ? my_bin[1] : my_bin[2])) <= split : (lane - a) < c / 2;
+        const unsigned long long ml = __ballot(in && left), mr = __ballot(in && !left);
+        const uint32_t n_left = (uint32_t)__popcll(ml);
+        if (n_left == 0 || n_left >= c) {  // the bins and the lanes disagree: internal error; leave a valid (if poor) tree
+            if (lane == 0) {
+                atomicOr(err, 4u);
+                nodes[node].left = -1;
+            }
+            continue;
+        }
+        // the children's boxes: unions of the triangles' boxes on either side (what the bins' unions are too)
+        uint32_t cbx[12];
+        for (int k = 0; k < 6; k++) {
+            const bool is_lo = k < 3;
+            const uint32_t none = is_lo ? 0xFFFFFFFFu : 0u;
+            const uint32_t vl = (in && left) ? bw[k] : none, vr = (in && !left) ? bw[k] : none;
+            cbx[k] = is_lo ? wave_min_u(vl) : wave_max_u(vl);
+            cbx[6 + k] = is_lo ? wave_min_u(vr) : wave_max_u(vr);
+        }
+        const uint32_t child = first_node + used;
+        used += 2u;
+        if (lane < 2) {
+            Node C;
+            C.lo = lo + (lane == 0 ? a : a + n_left);
+            C.hi = lo + (lane == 0 ? a + n_left : b);
+            C.left = -2;
+            C.n_left = 0;
+            C.axis = -1, C.split = 0;
+            for (int k = 0; k < 6; k++) C.box[k] = cbx[lane * 6 + k], C.cb[k] = (k < 3) ? 0xFFFFFFFFu : 0u;
+            C.depth = dep + 1u;
+            C.pad = 0u;
+            nodes[child + lane] = C;
+        }
+        if (lane == 0) {
+            nodes[node].left = (int32_t)child;
+            nodes[node].n_left = n_left;
+            nodes[node].axis = axis;
+            nodes[node].split = split;
+            S.stack[sp][0] = child + 1u, S.stack[sp][1] = a + n_left, S.stack[sp][2] = b, S.stack[sp][3] = dep + 1u;
+            S.stack[sp + 1][0] = child, S.stack[sp + 1][1] = a, S.stack[sp + 1][2] = a + n_left, S.stack[sp + 1][3] = dep + 1u;
+        }
+        sp += 2;
+        // stable partition of lanes [a, b): ranks from the ballots, registers through LDS
+        if (in) {
+            const unsigned long long below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+            const uint32_t to = left ? a + (uint32_t)__popcll(ml & below) : a + n_left + (uint32_t)__popcll(mr & below);
+            S.move[0][to] = t;
+            for (int k = 0; k < 6; k++) S.move[1 + k][to] = bw[k];
+            for (int x = 0; x < 3; x++) S.move[7 + x][to] = __float_as_uint(ce[x]);
+        }
+        SAH_LDS_SYNC();
+        if (in) {
+            t = S.move[0][lane];
+            for (int k = 0; k < 6; k++) bw[k] = S.move[1 + k][lane];
+            for (int x = 0; x < 3; x++) ce[x] = __uint_as_float(S.move[7 + x][lane]);
+        }
+        SAH_LDS_SYNC();
+    }
+    if (lane < cnt) order[lo + lane] = t;
+    for (uint32_t k = used + lane; k < block_nodes; k += 64) {  // the unused tail: leaves of nothing that nobody points to
+        Node U;
+        U.lo = U.hi = 0u;
+        U.left = -1;
+        U.n_left = 0u;
+        U.axis = -1, U.split = 0;
+        for (int q = 0; q < 6; q++) U.box[q] = U.cb[q] = (q < 3) ? 0xFFFFFFFFu : 0u;
+        U.depth = 0u, U.pad = 0u;
+        nodes[first_node + k] = U;
+    }
+    if (lane == 0 && deepest > *max_depth) atomicMax(max_depth, deepest);
+}
+
 // 5. inner nodes -> BvhNode (bvh_build.cpp:276-290: padded boxes of both children)
 __global__ __launch_bounds__(kBlock) void k_sah_mark_inner(const Node *nodes, uint32_t total, uint32_t *inner) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -445,7 +657,7 @@ int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_
         fprintf(stderr, "[sah] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count());
         T0 = t;
     };
-    const uint32_t capacity = 2 * n;           // node records
+    const uint32_t capacity = 4 * n + 64;      // node records: fewer than 2n in the tree; k_sah_small reserves 2 cnt - 2 per subtree and leaves some unused
     const uint32_t bin_slots = n / 2 + 64;     // nodes of one level (each inner node of a level holds more than kLeafMax triangles;
                                                // leaves of a level take a slot too, hence not n / 5)
     DBuf<float> d_pos, d_tb, d_cen;
@@ -456,7 +668,7 @@ int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_
     int rc;
     if ((rc = d_pos.ensure((size_t)n * 9)) || (rc = d_tb.ensure((size_t)n * 6)) || (rc = d_cen.ensure((size_t)n * 3)) || (rc = d_order.ensure(n)) ||
         (rc = d_order2.ensure(n)) || (rc = d_nodeof.ensure(n)) || (rc = d_nodeof2.ensure(n)) || (rc = d_flag.ensure(n + 1)) || (rc = d_rank.ensure(n + 1)) ||
-        (rc = d_bins.ensure((size_t)bin_slots * kBinWords)) || (rc = d_word.ensure(2)) || (rc = d_inner.ensure(capacity)) ||
+        (rc = d_bins.ensure((size_t)bin_slots * kBinWords)) || (rc = d_word.ensure(4)) || (rc = d_inner.ensure(capacity)) ||
         (rc = d_index.ensure(capacity)) || (rc = d_nodes.ensure(capacity)) || (rc = d_out.ensure(n)))
         return rc;
     size_t scan_bytes = 0, scan2_bytes = 0;
@@ -467,10 +679,10 @@ int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_
     RRT_HIP(hipMemcpy(d_pos.p, positions, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice));
     Node root;
     memset(&root, 0, sizeof(root));
-    root.lo = 0, root.hi = n, root.left = -2, root.axis = -1;
+    root.lo = 0, root.hi = n, root.left = -2, root.axis = -1, root.depth = 1;
     for (int k = 0; k < 3; k++) root.box[k] = root.cb[k] = 0xFFFFFFFFu, root.box[3 + k] = root.cb[3 + k] = 0u;
     RRT_HIP(hipMemcpy(d_nodes.p, &root, sizeof(root), hipMemcpyHostToDevice));
-    RRT_HIP(hipMemset(d_word.p, 0, 2 * sizeof(uint32_t)));
+    RRT_HIP(hipMemset(d_word.p, 0, 4 * sizeof(uint32_t)));  // [0] nodes a level created, [1] error bits, [2] nodes k_sah_small created, [3] its deepest node
     RRT_HIP(hipMemset(d_flag.p + n, 0, sizeof(uint32_t)));  // the scan runs over n + 1 entries: rank[n] = all left-going triangles
     lap("upload");
     hipEvent_t e0, e1;
@@ -510,6 +722,19 @@ int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_
         se = hipGetLastError();
     }
     uint32_t n_inner = 0;
+    if (se == hipSuccess && word[1] == 0) {  // the subtrees of the nodes the level rounds left at kSmall triangles or fewer
+        hipLaunchKernelGGL(k_sah_small, dim3((total + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, nullptr, d_nodes.p, total, capacity, order_a, d_tb.p,
+                           d_cen.p, d_word.p + 2, d_word.p + 3, d_word.p + 1);
+        uint32_t w4[4] = {0, 0, 0, 0};
+        se = hipGetLastError();
+        if (se == hipSuccess) se = hipMemcpy(w4, d_word.p, sizeof(w4), hipMemcpyDeviceToHost);
+        word[1] = w4[1];
+        if (se == hipSuccess && word[1] == 0) {
+            if (w4[2] > capacity - total) word[1] |= 2u;
+            total += w4[2];
+            levels = std::max(levels, w4[3]);
+        }
+    }
     if (se == hipSuccess && word[1] == 0) {
         hipLaunchKernelGGL(k_sah_mark_inner, grid_for(total), dim3(kBlock), 0, nullptr, d_nodes.p, total, d_inner.p);
         se = rocprim::exclusive_scan(d_temp.p, scan2_bytes, d_inner.p, d_index.p, 0u, (size_t)total, rocprim::plus<uint32_t>(), nullptr);
