@@ -359,6 +359,11 @@ def test_device_trace_code_in_the_wave_emulator(repo):
     out = subprocess.run([sys.executable, os.path.join(repo, "tools/cpu_emu/check_random_scenes.py"), "0", "6"], capture_output=True, text=True,
                          env=dict(os.environ, EMU_TEAPOTS="1"))
     assert out.returncode == 0 and "ALL OK" in out.stdout and "teapots: mesh hits" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    # a 101 120-triangle mesh: its tree is large enough for the threaded four-wide collapse (bvh_build.cpp: top breadth first,
+    # subtrees on host threads, spliced) and the sliced triangle records (runtime.cpp)
+    out = subprocess.run([sys.executable, os.path.join(repo, "tools/cpu_emu/check_random_scenes.py"), "0", "0"], capture_output=True, text=True,
+                         env=dict(os.environ, EMU_TEAPOTS="1", EMU_TEAPOT_GRID="4", EMU_RAYS="1024"))
+    assert out.returncode == 0 and "ALL OK" in out.stdout and "teapots: mesh hits" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     # CSG trees with MESH leaves (csg_object.rs:25-36): the BVH walk runs while hit lists are live (stack behind the lists),
     # and a mesh that meets no triangle can still hand the merge a plane's Hit::infinity (seed 2 has such meshes)
     out = subprocess.run([sys.executable, os.path.join(repo, "tools/cpu_emu/check_random_scenes.py"), "0", "4"], capture_output=True, text=True,

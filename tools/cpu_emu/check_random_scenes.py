@@ -16,7 +16,8 @@ def teapots(scene):
     """2 x 2 teapots (25 280 triangles: a tree deep enough for the four-wide collapse and the threaded SAH build to matter),
     smooth, plus a floor; rays come from around the grid."""
     import bench_extra
-    pos, nrm = bench_extra.teapot_grid(2, 2)
+    g = int(os.environ.get("EMU_TEAPOT_GRID", "2"))  # 4: 101 120 triangles, enough nodes for the threaded collapse (bvh_build.cpp)
+    pos, nrm = bench_extra.teapot_grid(g, g)
     m = kit.monochrome(scene, (0.7, 0.5, 0.3))
     scene.add_object(kit.mesh(scene, pos, nrm, m, True))
     scene.add_object(kit.plane(scene, (0.0, -0.5, 0.0), (0.0, 0.0, 1.0), (0.0, 1.0, 0.0), m))
@@ -34,7 +35,7 @@ for seed in seeds:
         except rrt.RrtError as e:
             assert e.code == abi.ERR_DEVICE, e
         cpu = teapots(ob.OracleScene())
-        o, d = kit.coherent_rays(3000, 5, origin_scale=60.0, towards=(0.0, 5.0, 0.0), spread=25.0)
+        o, d = kit.coherent_rays(int(os.environ.get("EMU_RAYS", "3000")), 5, origin_scale=60.0, towards=(0.0, 5.0, 0.0), spread=25.0)
         np.concatenate([o, d], axis=1).astype(np.float32).tofile(os.path.join(tmp, "rays.f32"))
         r = subprocess.run([emu, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "rays.f32"), os.path.join(tmp, "out.bin")], capture_output=True, text=True,
                            env=dict(os.environ, EMU_SHADOW_LIMIT="40"))
