@@ -2,8 +2,9 @@
 // (environments/photon_scene.rs:42-307, lights/{point_light,directional_point_light}.rs), and the
 // build of the hash-grid index the render pass gathers from (replaces core/photon_tree.rs).
 //
-//  k_photon_shoot   one lane per emitted photon; the Russian-roulette path is a loop (every branch
-//                   of PhotonScene::photontrace is a tail call).  Each landing stores the absorbed
+//  k_photon_shoot   one lane per photon in flight; the Russian-roulette path is a loop (every branch
+//                   of PhotonScene::photontrace is a tail call), and a lane whose path has ended takes
+//                   the next photon of its wave's run (the grid is what the GPU holds at once).  Each landing stores the absorbed
 //                   photon plus one shadow photon per entering surface behind it; records are
 //                   appended with one atomic per wave per destination (ballot + prefix popcount).
 //                   RNG = Philox4x32-10 keyed by (seed, light, pass, photon index): the record SET
@@ -86,7 +87,14 @@ __device__ __forceinline__ void store_photon(const PhotonOut &o, bool want, f3 p
     o.meta[slot] = meta;
 }
 
-__global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
+// Three waves per SIMD (168 VGPRs, 400 bytes of spills per lane): the kernel is one long chain of traces per photon and
+// waits on memory half of the time; left to itself the compiler takes all 256 registers and one wave per SIMD runs.
+// Measured on scene2, 1 M photons: 1 / 2 / 3 / 4 waves 2.82 / 1.93 / 1.76 / 2.13 ms (the hit lists' LDS allows three);
+// with lanes refilled from the wave's run of photons (below) 1.5 ms.
+#ifndef RRT_SHOOT_WAVES
+#define RRT_SHOOT_WAVES 3
+#endif
+__global__ __launch_bounds__(RRT_BLOCK, RRT_SHOOT_WAVES) void k_photon_shoot(ShootArgs A) {
     const DevScene &S = A.S;
     Lds lds;
     lds.nthreads = RRT_BLOCK;
@@ -94,17 +102,44 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
     lds.le = reinterpret_cast<float2 *>(g_smem_ph);
     lds.stack = reinterpret_cast<int *>(g_smem_ph);
     lds.stack_base = (S.has_csg & 2u) ? A.lds_slots * RRT_LIST_CAP : 0u;  // see make_lds (kernels.hip)
-    uint32_t gid = blockIdx.x * RRT_BLOCK + threadIdx.x;
-    bool alive = gid < A.count;
+    // Each wave owns a run of photons [next, end) and deals them to its lanes as they fall free: a path ends after 1.7
+    // landings on average but the longest of 64 takes many more, and a lane whose photon is absorbed would idle until then
+    // (34 % of the lanes were busy when a VALU instruction issued).  A photon's records depend on its index alone (RNG
+    // stream, keys), so which lane traces it, and when, changes nothing.
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * (RRT_BLOCK / 64u), wave_id = blockIdx.x * (RRT_BLOCK / 64u) + (threadIdx.x >> 6);
+    const uint32_t per_wave = (A.count + n_waves - 1u) / n_waves;
+    uint32_t next = (uint32_t)min((uint64_t)wave_id * per_wave, (uint64_t)A.count);
+    const uint32_t end = (uint32_t)min((uint64_t)next + per_wave, (uint64_t)A.count);
+    bool alive = false;
+    uint32_t bounce = 0;
     Counters cnt = {0, 0, 0, 0};
     uint32_t err = 0;
-    uint64_t index = A.first + gid;
+    uint64_t index = 0;
     const uint64_t tag = (uint64_t)(A.light * 2 + A.pass) << 56;
     const DevLight L = S.lights[A.light];
     Philox rng;
-    rng_init(rng, A.seed, A.light, A.pass, index);
+    rng_init(rng, A.seed, A.light, A.pass, 0);
     f3 origin = L.position, dir = mk3(0, 0, 1), intensity = L.intensity;
-    if (alive) {
+    const int dest_absorb_default = A.pass == 1 ? 1 : 0;
+    for (;;) {
+      // ---- free lanes take the wave's next photons (light.rs:28-72: emission) ----
+      bool take = false;
+      {
+        const unsigned long long idle = __ballot(!alive);
+        const uint32_t avail = end - next;
+        if (idle && avail) {
+            const uint32_t rank = (uint32_t)__popcll(idle & (lane == 0 ? 0ULL : (~0ULL >> (64 - lane))));
+            take = !alive && rank < avail;
+            if (take) index = A.first + next + rank;
+            next += min((uint32_t)__popcll(idle), avail);
+        }
+      }
+      if (take) {
+        alive = true;
+        bounce = 0;
+        rng_init(rng, A.seed, A.light, A.pass, index);
+        origin = L.position, intensity = L.intensity;
         f3 direction;
         if (A.pass == 0) {
             if (L.kind == RRT_LIGHT_POINT) {  // point_light.rs:61-70
@@ -129,10 +164,9 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
             }
         }
         dir = norm3(direction);
-    }
-    const int dest_absorb_default = A.pass == 1 ? 1 : 0;
-    for (uint32_t bounce = 0; bounce < A.max_bounces; bounce++) {
-        if (!__any(alive)) break;
+      }
+      if (!__any(alive)) break;  // and none left to take: `take` would have set a lane alive
+      {
         // PhotonScene::photontrace, photon_scene.rs:150-186
         TraceResult tr;
         tr.object = 0xFFFFFFFFu;
@@ -262,6 +296,9 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_photon_shoot(ShootArgs A) {
                 }
             }
         }
+        // a photon lands at most max_bounces times (the cap of the reference's unbounded recursion, rrt.h)
+        if (alive && ++bounce >= A.max_bounces) alive = false;
+      }
     }
     unsigned long long n = cnt.nodes, t = cnt.tris;
 #pragma unroll
@@ -779,7 +816,16 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         A.err = s->counters.p + 63;
         A.stats = s->stats_dev.p;
         RRT_HIP(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(k_photon_shoot, grid_for(count, RRT_BLOCK), dim3(RRT_BLOCK), s->dev.lds_bytes, nullptr, A);
+        // as many blocks as the GPU holds at once (or fewer, for few photons): every wave then works through a run of
+        // photons of its own, refilling its lanes as paths end (k_photon_shoot)
+        dim3 shoot_grid = grid_for(count, RRT_BLOCK);
+        {
+            int per_cu = 0, dev = 0, n_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_photon_shoot, RRT_BLOCK, s->dev.lds_bytes) == hipSuccess && per_cu > 0 &&
+                hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
+                shoot_grid.x = std::min<uint32_t>(shoot_grid.x, (uint32_t)per_cu * (uint32_t)n_cu);  // (2x / 4x as many, shorter runs: 2 / 10 % slower)
+        }
+        hipLaunchKernelGGL(k_photon_shoot, shoot_grid, dim3(RRT_BLOCK), s->dev.lds_bytes, nullptr, A);
         RRT_HIP(hipGetLastError());
         uint32_t err = 0;
         std::vector<uint32_t> raw(2 * PH_SEGMENTS * PH_COUNT_STRIDE);
