@@ -14,7 +14,7 @@
 // The host reads one word per level (how many nodes the level created) and stops when it is zero.  Nodes of at most 64
 // triangles leave the rounds early: k_sah_small finishes each such subtree with one wave, bins and partition in LDS.
 //
-// Memory is spent freely (MI355X: 288 GB): 4n node records, one 1344-byte bin block per node of the widest level.
+// Memory is spent freely (MI355X: 288 GB): 4n node records of 72 bytes, a 1344-byte bin block for each of n / 16 level nodes.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -658,8 +658,8 @@ int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_
         T0 = t;
     };
     const uint32_t capacity = 4 * n + 64;      // node records: fewer than 2n in the tree; k_sah_small reserves 2 cnt - 2 per subtree and leaves some unused
-    const uint32_t bin_slots = n / 2 + 64;     // nodes of one level (each inner node of a level holds more than kLeafMax triangles;
-                                               // leaves of a level take a slot too, hence not n / 5)
+    const uint32_t bin_slots = n / 16 + 64;    // nodes of one level: the children of nodes of more than kSmall triangles, so fewer than
+                                               // 2 n / 65; twice that is reserved (a wider level is refused, not overrun)
     DBuf<float> d_pos, d_tb, d_cen;
     DBuf<uint32_t> d_order, d_order2, d_nodeof, d_nodeof2, d_flag, d_rank, d_bins, d_word, d_inner, d_index;
     DBuf<Node> d_nodes;
