@@ -652,8 +652,19 @@ static int build_index(rrt_scene *s, int which) {
     if (!(cell > 0.0f) || !std::isfinite(X.inv_dcell)) return fail(RRT_ERR_INVALID, "gather_half_width must be positive");
     int rc;
     PhotonScratch &W = s->photon_scratch;
+    const bool timing = getenv("RRT_INDEX_INFO") != nullptr;  // debugging aid: host wall clock of the phases (each ends in a sync)
+    auto t_phase = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[index %d] %-22s %7.3f ms\n", which, what, std::chrono::duration<double, std::milli>(t - t_phase).count());
+        t_phase = t;
+    };
     if ((rc = sort_by_meta(W, b))) return rc;  // canonical order first; the cell sort below is stable
+    lap("sort by key + permute");
     if ((rc = choose_dense_grids(s, b, n, cell, X))) return rc;
+    lap("choose dense grids");
     const uint32_t cells = X.dense_cells;
     DBuf<uint64_t> &keys = W.keys, &keys2 = W.keys2;
     DBuf<uint32_t> &idx = W.idx, &idx2 = W.idx2, &ncell = W.ncell;
@@ -668,6 +679,7 @@ static int build_index(rrt_scene *s, int which) {
     hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.rgb.p, idx2.p, n, X.rgb.p);
     if ((rc = X.meta.ensure(n))) return rc;
     hipLaunchKernelGGL(k_gather<uint64_t>, grid_for(n), dim3(256), 0, nullptr, b.meta.p, idx2.p, n, X.meta.p);
+    lap("cell sort + permute");
     // dense part: the start table, and where the outliers begin
     if ((rc = X.dense_start.ensure((size_t)cells + 1))) return rc;
     uint32_t *n_dense_dev = ncell.p + PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE;
@@ -704,6 +716,7 @@ static int build_index(rrt_scene *s, int which) {
         for (int k = 0; k < 64; k++) sum += part[k * 8];
         X.crowding = (double)sum / (double)n;
     }
+    lap("tables + crowding");
     if (getenv("RRT_INDEX_INFO")) {
         fprintf(stderr, "[index %d] %u records: %u in %u dense grids (cell %.3g, %u cells), %u outliers in %u hash cells; crowding %.1f\n", which, n,
                 n_dense, X.n_grids, cell, cells, n_out, out_cells, X.crowding);
