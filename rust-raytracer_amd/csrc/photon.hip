@@ -559,6 +559,7 @@ static void choose_dense_box(const std::vector<std::array<float, 3>> &pts, doubl
         }
     }
     auto cells_of = [&](int a) { return std::max(1.0, std::ceil((hi[a] - lo[a]) / (double)cell) + 4.0); };
+    std::vector<std::array<float, 3>> inside(pts);  // the box only shrinks: a sample that has left it never counts again
     for (int it = 0; it < 400 && cells_of(0) * cells_of(1) * cells_of(2) > budget; it++) {
         double cut[6];  // new position of face 2a (low) / 2a + 1 (high)
         uint32_t loss[6] = {0, 0, 0, 0, 0, 0};
@@ -566,13 +567,16 @@ static void choose_dense_box(const std::vector<std::array<float, 3>> &pts, doubl
             cut[2 * a] = lo[a] + 0.2 * (hi[a] - lo[a]);
             cut[2 * a + 1] = hi[a] - 0.2 * (hi[a] - lo[a]);
         }
-        for (const auto &p : pts) {
+        size_t kept = 0;
+        for (const auto &p : inside) {
             if (!(p[0] >= lo[0] && p[0] <= hi[0] && p[1] >= lo[1] && p[1] <= hi[1] && p[2] >= lo[2] && p[2] <= hi[2])) continue;
+            inside[kept++] = p;
             for (int a = 0; a < 3; a++) {
                 if (p[a] < cut[2 * a]) loss[2 * a]++;
                 if (p[a] > cut[2 * a + 1]) loss[2 * a + 1]++;
             }
         }
+        inside.resize(kept);
         int best = -1;
         for (int f = 0; f < 6; f++) {
             if (cells_of(f / 2) <= 8.0) continue;  // an axis this thin is not what makes the grid large
