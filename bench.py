@@ -318,6 +318,14 @@ def main():
                 extra.update(bench_extra.run(rrt, torch))
                 ms3 = bench_extra.frames_in_flight_ms(torch, scene, cam, 30)
                 out["config"]["value_3_frames_in_flight"] = (total_rays / args.steps) / (ms3 * 1e-3) / 1e6
+                # the same scene flattened once more, warm (pre_render_s / ms_bvh_build above include the first use of the
+                # builder's kernels in this process)
+                scene2, _, _ = bench_extra.build_mesh_scene(rrt, variant=args.variant)
+                t0 = time.perf_counter()
+                scene2.pre_render(seed=1)
+                out["config"]["pre_render_warm_s"] = time.perf_counter() - t0
+                out["config"]["ms_bvh_build_warm"] = scene2.stats()["ms_bvh_build"]
+                del scene2
             except Exception as e:
                 extra["error"] = repr(e)
         if extra:
