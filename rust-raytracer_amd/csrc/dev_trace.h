@@ -86,7 +86,37 @@ struct LaneStack {
 
 struct Counters {
     uint32_t nodes, tris, shadow, overflow;
+#ifdef RRT_WALK_STATS  // instrumentation builds only (tools/walk_stats.sh): three 64-bit sums that travel in the photon statistics' slots
+    unsigned long long ws[3] = {0, 0, 0};
+#endif
 };
+#ifdef RRT_WALK_STATS
+// one count per WAVE for the code path that executes this (the first active lane counts)
+#define RRT_WS_WAVE_COUNT(slot)                                                                  \
+    do {                                                                                         \
+        const unsigned long long m_ = __ballot(1);                                               \
+        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m_) - 1u) cnt.ws[slot] += 1ull;  \
+    } while (0)
+// wave-level time stamps between the phases of k_trace_shade (RRT_WALK_STATS 3, 4): the first active lane adds the difference
+#define RRT_WS_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define RRT_WS_ADD(slot, dt)                                                                     \
+    do {                                                                                         \
+        const unsigned long long m_ = __ballot(1);                                               \
+        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m_) - 1u) cnt.ws[slot] += (dt);  \
+    } while (0)
+#else
+#define RRT_WS_WAVE_COUNT(slot)
+#define RRT_WS_STAMP(var)
+#define RRT_WS_ADD(slot, dt)
+#endif
+#ifndef RRT_WALK_LOG  // tools/cpu_emu/walk_trace.cpp records every step of a walk: 0 = node visit, n = leaf of n triangles
+#define RRT_WALK_LOG(step)
+#endif
+#if RRT_WALK_STATS == 1
+#define RRT_WS_TICK(w) (w).ws_last = __builtin_amdgcn_s_memtime()
+#else
+#define RRT_WS_TICK(w)
+#endif
 
 struct TraceResult {
     float t;
@@ -289,90 +319,160 @@ __device__ __forceinline__ void order2(float &ka, int &ca, float &kb, int &cb) {
     cb = c;
 }
 
+// One lane's walk through a mesh's BVH, as a state that can be advanced step by step: mesh_closest runs one walk to its
+// end (the pooled-walk experiment, tools/experiments/pool_kernel.patch, kept 64 of them going and handed a lane whose
+// walk was over the next ray; tools/cpu_emu/walk_trace.cpp records the steps).
+// "While-while" order: walk_nodes takes a lane down through inner nodes until it holds a leaf (or is done); the wave
+// leaves that loop when no lane has a node left, and only then walk_leaf tests the leaves' triangles, for all lanes that
+// hold one.
+#define RRT_WALK_DONE ((int)0x80000000)  // as a leaf code its first triangle is beyond every mesh (meshes hold < 2^27 triangles)
+struct MeshView {  // what the loops read of a MeshInfo, in registers (M is memory the loops would re-read)
+    const BvhNodeQ *nodes;
+    const TriHot *tris;
+    const uint32_t *orig;
+    uint32_t node_count, tri_count;
+};
+__device__ __forceinline__ MeshView mesh_view(const DevScene &S, const MeshInfo &M) {
+    return MeshView{S.nodes + M.node_first, S.tris + M.tri_first, S.tri_index + M.tri_first, M.node_count, M.tri_count};
+}
+struct Walk {
+    f3 o, d;
+    RaySlabs slabs;
+    float best;  // distance of the nearest hit accepted so far; the bound the walk started with until there is one
+    uint32_t best_orig, best_slot;
+    bool best_entering, found;
+    bool ties;  // a hit AT the starting bound is accepted too (for a bound that is the hit of a LATER object record, which loses ties)
+    int cur;    // >= 0: inner node, < 0: leaf code, RRT_WALK_DONE: the walk is over
+#if RRT_WALK_STATS == 1
+    unsigned long long ws_last;  // s_memtime of the lane's last step
+#endif
+};
+__device__ __forceinline__ void walk_begin(Walk &w, const MeshInfo &M, f3 o, f3 d, float tmax, bool ties) {
+    w.o = o;
+    w.d = d;
+    w.slabs = make_slabs(M, o, d);
+    w.best = tmax;
+    w.best_orig = 0xFFFFFFFFu;
+    w.best_slot = 0;
+    w.best_entering = w.found = false;
+    w.ties = ties;
+    w.cur = M.tri_count ? 0 : RRT_WALK_DONE;  // root
+}
+// one node visit of a lane that holds an inner node: four children tested, the nearest hit one next, the others stacked
+template <bool PLAIN_STACK>
+__device__ __forceinline__ void walk_node_step(const MeshView &V, Walk &w, LaneStack<PLAIN_STACK> &stack, Counters &cnt) {
+    if ((uint32_t)w.cur >= V.node_count) {
+        cnt.overflow |= 16u;
+        w.cur = RRT_WALK_DONE;
+        return;
+    }
+#if RRT_WALK_STATS == 2
+    RRT_WS_WAVE_COUNT(0);
+#endif
+    RRT_WS_TICK(w);  // (inside the loop: a stamp taken on the way out would be sunk behind the loop's exit)
+    RRT_WALK_LOG(0u);
+    const BvhNodeQ N = *reinterpret_cast<const BvhNodeQ *>(reinterpret_cast<const char *>(V.nodes) + ((uint32_t)w.cur << 6));
+    int c0 = N.child[0], c1 = N.child[1], c2 = N.child[2], c3 = N.child[3];
+    float k0, k1, k2, k3;
+    const bool h0 = box_test(N.q[0], N.q[4], N.q[8], w.slabs, w.best, k0);
+    const bool h1 = box_test(N.q[1], N.q[5], N.q[9], w.slabs, w.best, k1);
+    const bool h2 = box_test(N.q[2], N.q[6], N.q[10], w.slabs, w.best, k2);
+    const bool h3 = box_test(N.q[3], N.q[7], N.q[11], w.slabs, w.best, k3);
+    cnt.nodes += 4;
+    k0 = h0 ? k0 : RRT_INF, k1 = h1 ? k1 : RRT_INF, k2 = h2 ? k2 : RRT_INF, k3 = h3 ? k3 : RRT_INF;
+    // the nearest child first; the other three go on the stack as they come (ordering them as well costs two more
+    // exchanges per visit and buys nothing measurable: 0.998 -> 0.989 ms on the 4K mesh frame without)
+    order2(k0, c0, k1, c1);
+    order2(k2, c2, k3, c3);
+    order2(k0, c0, k2, c2);
+    if (k3 < RRT_INF) stack.push(c3);
+    if (k2 < RRT_INF) stack.push(c2);
+    if (k1 < RRT_INF) stack.push(c1);
+    if (k0 < RRT_INF)
+        w.cur = c0;
+    else if (stack.empty())
+        w.cur = RRT_WALK_DONE;
+    else
+        w.cur = stack.pop();
+}
+template <bool PLAIN_STACK>
+__device__ __forceinline__ void walk_nodes(const MeshView &V, Walk &w, LaneStack<PLAIN_STACK> &stack, Counters &cnt) {
+    while (w.cur >= 0) walk_node_step(V, w, stack, cnt);
+}
+// the triangles of the leaf the lane holds (Triangle::intersect for each, the reference's test bit for bit), then the next
+// node off the stack
+template <bool PLAIN_STACK>
+__device__ __forceinline__ void walk_leaf(const MeshView &V, Walk &w, LaneStack<PLAIN_STACK> &stack, Counters &cnt) {
+#if RRT_WALK_STATS == 2
+    RRT_WS_WAVE_COUNT(2);
+#endif
+    const uint32_t code = (uint32_t)(-(w.cur + 1));
+    const uint32_t first = code >> 4, n = code & 15u;
+    if (first + n > V.tri_count) {
+        cnt.overflow |= 16u;
+        w.cur = RRT_WALK_DONE;  // index guard, as in walk_nodes: give up the walk
+        return;
+    }
+    RRT_WALK_LOG(n);
+    for (uint32_t k = 0; k < n; k++) {
+        const TriHot T = V.tris[first + k];
+        float t;
+        bool ent;
+        cnt.tris++;
+#if RRT_WALK_STATS == 2
+        RRT_WS_WAVE_COUNT(1);
+#endif
+        if (!tri_test(T, w.o, w.d, t, ent)) continue;
+        if (t < 0.0f) continue;
+        const uint32_t oi = V.orig[first + k];
+        if (t < w.best || ((w.found || w.ties) && t == w.best && oi < w.best_orig)) {
+            w.found = true;
+            w.best = t;
+            w.best_orig = oi;
+            w.best_slot = first + k;
+            w.best_entering = ent;
+        }
+    }
+    RRT_WS_TICK(w);
+    w.cur = stack.empty() ? RRT_WALK_DONE : stack.pop();
+}
+
 // PolyMesh::intersect (polymesh_object.rs:216-242): the closest hit of EITHER facing with t >= 0,
 // the lowest triangle index winning exact ties; only hits with t < tmax are reported (callers pass
 // the best distance so far: a farther mesh hit could not win anyway).  Returns the BVH slot.
 template <bool PLAIN_STACK = false>
 __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &M, f3 o, f3 d, float tmax, Lds &lds, Counters &cnt,
                                              float &best_t, uint32_t &best_slot, bool &best_entering) {
-    const RaySlabs slabs = make_slabs(M, o, d);
-    bool found = false;
-    float best = tmax;
-    uint32_t best_orig = 0xFFFFFFFFu;
-    best_slot = 0;
-    best_entering = false;
-    const BvhNodeQ *nodes = S.nodes + M.node_first;
-    const TriHot *tris = S.tris + M.tri_first;
-    const uint32_t *orig = S.tri_index + M.tri_first;
-    const uint32_t node_count = M.node_count, tri_count = M.tri_count;  // locals: M is memory the loop would re-read
+    const MeshView V = mesh_view(S, M);
     LaneStack<PLAIN_STACK> stack{lds, 0u};
-    int cur = 0;  // root
-    if (tri_count == 0) return false;
-    // "while-while" order: a lane descends through inner nodes until it holds a leaf (or is done); the wave leaves the
-    // inner loop when no lane has a node left, and only then are the leaves' triangles tested, by all lanes that hold one.
-    const int DONE = (int)0x80000000;  // as a leaf code its first triangle is beyond every mesh
-    for (;;) {
-        while (cur >= 0) {
-            if ((uint32_t)cur >= node_count) {
-                cnt.overflow |= 16u;
-                cur = DONE;
-                break;
-            }
-            const BvhNodeQ N = *reinterpret_cast<const BvhNodeQ *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)cur << 6));
-            int c0 = N.child[0], c1 = N.child[1], c2 = N.child[2], c3 = N.child[3];
-            float k0, k1, k2, k3;
-            const bool h0 = box_test(N.q[0], N.q[4], N.q[8], slabs, best, k0);
-            const bool h1 = box_test(N.q[1], N.q[5], N.q[9], slabs, best, k1);
-            const bool h2 = box_test(N.q[2], N.q[6], N.q[10], slabs, best, k2);
-            const bool h3 = box_test(N.q[3], N.q[7], N.q[11], slabs, best, k3);
-            cnt.nodes += 4;
-            k0 = h0 ? k0 : RRT_INF, k1 = h1 ? k1 : RRT_INF, k2 = h2 ? k2 : RRT_INF, k3 = h3 ? k3 : RRT_INF;
-            // the nearest child first; the other three go on the stack as they come (ordering them as well costs two more
-            // exchanges per visit and buys nothing measurable: 0.998 -> 0.989 ms on the 4K mesh frame without)
-            order2(k0, c0, k1, c1);
-            order2(k2, c2, k3, c3);
-            order2(k0, c0, k2, c2);
-            if (k3 < RRT_INF) stack.push(c3);
-            if (k2 < RRT_INF) stack.push(c2);
-            if (k1 < RRT_INF) stack.push(c1);
-            if (k0 < RRT_INF)
-                cur = c0;
-            else if (stack.empty())
-                cur = DONE;
-            else
-                cur = stack.pop();
-        }
-        if (cur == DONE) break;
-        {
-            uint32_t code = (uint32_t)(-(cur + 1));
-            uint32_t first = code >> 4, n = code & 15u;
-            if (first + n > tri_count) {
-                cnt.overflow |= 16u;
-                cur = DONE;  // index guard, as above: give up the walk
-                break;
-            }
-            for (uint32_t k = 0; k < n; k++) {
-                const TriHot T = tris[first + k];
-                float t;
-                bool ent;
-                cnt.tris++;
-                if (!tri_test(T, o, d, t, ent)) continue;
-                if (t < 0.0f) continue;
-                uint32_t oi = orig[first + k];
-                if (t < best || (found && t == best && oi < best_orig)) {
-                    found = true;
-                    best = t;
-                    best_orig = oi;
-                    best_slot = first + k;
-                    best_entering = ent;
-                }
-            }
-        }
-        if (stack.empty()) break;
-        cur = stack.pop();
+    Walk w;
+    walk_begin(w, M, o, d, tmax, false);
+#if RRT_WALK_STATS == 1  // time a lane spends in the walk against the time its wave does (primary rays, or shadow rays with RRT_WS_SHADOW)
+#ifdef RRT_WS_SHADOW
+    const bool ws_on = !(tmax > 1e30f);
+#else
+    const bool ws_on = tmax > 1e30f;
+#endif
+    const unsigned long long ws_t0 = __builtin_amdgcn_s_memtime();
+    w.ws_last = ws_t0;
+#endif
+    while (w.cur != RRT_WALK_DONE) {
+        walk_nodes(V, w, stack, cnt);
+        if (w.cur == RRT_WALK_DONE) break;
+        walk_leaf(V, w, stack, cnt);
     }
-    best_t = best;
-    return found;
+#if RRT_WALK_STATS == 1
+    if (ws_on) {
+        const unsigned long long ws_t1 = __builtin_amdgcn_s_memtime();
+        cnt.ws[0] += w.ws_last - ws_t0;
+        cnt.ws[1] += ws_t1 - ws_t0;
+        cnt.ws[2] += 1ull;
+    }
+#endif
+    best_t = w.best;
+    best_slot = w.best_slot;
+    best_entering = w.best_entering;
+    return w.found;
 }
 
 // ---- CSG: per-ray interval lists (csg_object.rs:39-108) ---------------------------------------------

@@ -168,201 +168,179 @@ __device__ __forceinline__ f3 scene_node_total(f3 once, uint32_t flags, float wr
 #ifndef RRT_MIN_WAVES
 #define RRT_MIN_WAVES 3
 #endif
-// MODE is a template parameter so that the raytracing-mode instance does not carry the registers of the photon
-// gather and vice versa (occupancy is VGPR-limited here).
-// BLOCK: threads per block, 64 or 256 (launch_trace_shade says which and why).
-// FUSE: single-level frames (TraceArgs.fuse; raytracing mode only): a compile-time constant so that this instance carries
-// neither the child-ray state nor the node arrays' addresses across the shadow traversal.
-template <int MODE, int FEAT, int BLOCK, bool FUSE>
-__global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
-    const DevScene &S = A.S;
-    Lds lds = make_lds(A.S, A.lds_slots, BLOCK);
-    uint32_t block = blockIdx.x;
-    uint32_t i = block * BLOCK + threadIdx.x;
-    uint32_t count = A.count_ptr ? min(*A.count_ptr, A.count) : A.count;
-    bool active = i < count;
-    if (block * BLOCK >= count) return;  // launched for the predicted size of the level
-    Counters cnt = {0, 0, 0, 0};
-    unsigned long long gathered = 0, queries = 0, candidates = 0;
+
+// What a lane carries out of shade_node into the block-wide tail of the kernel (child rays, a deferred radiance estimate).
+struct NodeOut {
     bool want_a = false, want_b = false;  // a: reflection child, b: refraction child
-    f3 ao = mk3(0, 0, 0), ad = mk3(0, 0, 0), bo = mk3(0, 0, 0), bd = mk3(0, 0, 0);
+    f3 ao, ad, bo, bd;
     bool defer = false;  // photon mode: this lane's radiance estimate goes to k_gather_heavy
     HitAttr h;
-    f3 o, d;
-    h.material = 0;
+};
+struct GatherCounts {
+    unsigned long long gathered = 0, queries = 0, candidates = 0;
+};
 
-    if (active) {
-        level_ray(A, i, o, d);
-        TraceResult tr;
-        trace<FEAT>(S, o, d, lds, cnt, tr);
-        if (tr.object != 0xFFFFFFFFu) {
-            eval_hit<FEAT>(S, o, d, tr.instr, tr.sub, tr.t, h);
-            if ((uint32_t)h.material >= S.n_materials) {  // index guard of eval_hit tripped
-                cnt.overflow |= RRT_ERR_BIT_INTERNAL;
-                tr.object = 0xFFFFFFFFu;
-            }
+// Everything Scene::raytrace / PhotonScene::vueontrace do with the hit of ray (o, d), node i of the level: hit attributes,
+// local shading terms, the per-light loop, the child rays a Global part asks for.  `occluded(l, so, sd, limit)` answers
+// Scene::shadowtrace for light l (k_trace_shade traces the shadow ray there and then; the pooled-walk experiment,
+// tools/experiments/pool_kernel.patch, had traced it before and looked the answer up).
+template <int MODE, int FEAT, bool FUSE, class Occluded>
+__device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o, f3 d, TraceResult tr, Counters &cnt, GatherCounts &gc, NodeOut &N,
+                                           Occluded occluded) {
+    const DevScene &S = A.S;
+    HitAttr &h = N.h;
+    if (tr.object != 0xFFFFFFFFu) {
+        eval_hit<FEAT>(S, o, d, tr.instr, tr.sub, tr.t, h);
+        if ((uint32_t)h.material >= S.n_materials) {  // index guard of eval_hit tripped
+            cnt.overflow |= RRT_ERR_BIT_INTERNAL;
+            tr.object = 0xFFFFFFFFu;
         }
-        // Fused single-level frames (A.fuse: raytracing mode, no material spawns rays, so level 0 is the whole
-        // recursion): the pixel is finished here with k_combine's arithmetic and nothing goes through the node arrays.
-        constexpr bool fuse = MODE == RRT_MODE_SCENE && FUSE;
-        const uint32_t out_pixel = fuse ? (A.cam.width ? node_pixel(A.pixel_base + i, A.cam.width, A.band_rows, A.tile_order != 0u) : A.pixel_base + i) : 0u;
-        if (tr.object == 0xFFFFFFFFu) {  // scene.rs:85-90 / photon_scene.rs:311-313
-            if (fuse) {
-                write_pixel(A, out_pixel, mk3(0.0f, 0.0f, 0.0f), 0.0f, 0xFFFFFFFFu);
-            } else {
-                A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                A.cur.glob[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
-                A.cur.object_id[i] = 0xFFFFFFFFu;
-            }
+    }
+    // Fused single-level frames (A.fuse: raytracing mode, no material spawns rays, so level 0 is the whole
+    // recursion): the pixel is finished here with k_combine's arithmetic and nothing goes through the node arrays.
+    constexpr bool fuse = MODE == RRT_MODE_SCENE && FUSE;
+    const uint32_t out_pixel = fuse ? (A.cam.width ? node_pixel(A.pixel_base + i, A.cam.width, A.band_rows, A.tile_order != 0u) : A.pixel_base + i) : 0u;
+    if (tr.object == 0xFFFFFFFFu) {  // scene.rs:85-90 / photon_scene.rs:311-313
+        if (fuse) {
+            write_pixel(A, out_pixel, mk3(0.0f, 0.0f, 0.0f), 0.0f, 0xFFFFFFFFu);
         } else {
-            const DevMaterial &M = S.materials[h.material];
-            uint32_t flags = NF_HIT;
-            float kr = 0.0f;
-            if (!fuse) {
-                A.cur.object_id[i] = tr.object;
-                A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, tr.t);  // depth = hit.distance (scene.rs:124-127)
+            A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            A.cur.glob[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+            A.cur.object_id[i] = 0xFFFFFFFFu;
+        }
+        return;
+    }
+    const DevMaterial &M = S.materials[h.material];
+    uint32_t flags = NF_HIT;
+    float kr = 0.0f;
+    if (!fuse) {
+        A.cur.object_id[i] = tr.object;
+        A.cur.result[i] = make_float4(0.0f, 0.0f, 0.0f, tr.t);  // depth = hit.distance (scene.rs:124-127)
+    }
+    if (MODE == RRT_MODE_SCENE) {
+        f3 once = material_once_pre(S, M, h, cnt);
+        const float div = M.is_compound ? (float)M.n_parts : 0.0f;
+        f3 colour = mk3(0.0f, 0.0f, 0.0f);
+        // (a fused frame has no material with a Global part: that is what makes it single-level)
+        if (fuse) colour = scene_node_total(once, flags, 0.0f, 0.0f, div, kr, false, colour, false, colour);
+        // scene.rs:96-122
+        for (uint32_t l = 0; l < S.n_lights; l++) {
+            const DevLight L = S.lights[l];
+            f3 viewer = -norm3(h.position);  // eye assumed at the origin
+            f3 ldir;
+            bool lit = light_direction(L, h.position, ldir);
+            if (lit && dot3(ldir, h.normal) > 0.0f) lit = false;
+            if (lit) {
+                f3 sd = -ldir;
+                f3 so = h.position + sd * 0.0001f;
+                if (occluded(l, so, sd, len3(ldir))) lit = false;
             }
-            if (MODE == RRT_MODE_SCENE) {
-                f3 once = material_once_pre(S, M, h, cnt);
-                const float div = M.is_compound ? (float)M.n_parts : 0.0f;
-                f3 colour = mk3(0.0f, 0.0f, 0.0f);
-                // (a fused frame has no material with a Global part: that is what makes it single-level)
-                if (fuse) colour = scene_node_total(once, flags, 0.0f, 0.0f, div, kr, false, colour, false, colour);
-                // scene.rs:96-122
-                for (uint32_t l = 0; l < S.n_lights; l++) {
-                    const DevLight L = S.lights[l];
-                    f3 viewer = -norm3(h.position);  // eye assumed at the origin
-                    f3 ldir;
-                    bool lit = light_direction(L, h.position, ldir);
-                    if (lit && dot3(ldir, h.normal) > 0.0f) lit = false;
-                    if (lit) {
-                        f3 sd = -ldir;
-                        f3 so = h.position + sd * 0.0001f;
-                        if (shadowtrace<FEAT>(S, so, sd, len3(ldir), lds, cnt)) lit = false;
-                    }
-                    f3 term = mk3(0.0f, 0.0f, 0.0f);
-                    if (lit) term = material_per_light(S, M, h, viewer, ldir, cnt) * light_intensity(L, h.position);
-                    if (fuse) {
-                        if (lit) colour = colour + term;  // scene.rs:116-121, as k_combine adds them
-                    } else {
-                        A.cur.lights[(size_t)l * A.cur.capacity + i] = make_float4(term.x, term.y, term.z, lit ? 1.0f : 0.0f);
-                    }
-                }
-                if (fuse) {
-                    write_pixel(A, out_pixel, colour, tr.t, tr.object);
-                } else {
-                    // the child rays come after the light loop: nothing of them is live across the shadow traversals
-                    float wr = 0.0f, wt = 0.0f;
-                    if (M.global_part >= 0) {  // GlobalMaterial::compute_once, global_material.rs:71-98
-                        const MatPart &G = M.parts[M.global_part];
-                        flags |= NF_HAS_GLOBAL;
-                        wr = G.wr;
-                        wt = G.wt;
-                        if (A.level < A.max_depth) {
-                            flags |= NF_GLOBAL_ACTIVE;
-                            if (wr > 0.0f) {
-                                ad = norm3(reflect3(h.normal, d));
-                                ao = h.position + ad * 0.0001f;
-                                want_a = true;
-                            }
-                            if (wt > 0.0f) want_b = global_refraction(G, h, true, d, bo, bd, kr);
-                        }
-                    }
-                    A.cur.once[i] = make_float4(once.x, once.y, once.z, kr);
-                    A.cur.glob[i] = make_float4(wr, wt, div, __uint_as_float(flags));
-                }
-            } else {  // PhotonScene::vueontrace, photon_scene.rs:309-361
-                float sw = M.surface_weight, rw = M.w[3];
-                f3 surface = mk3(0.0f, 0.0f, 0.0f);
-                if (sw > 0.0f) {
-                    f3 inc, inten;
-                    queries += 2;
-                    const int got = average_photon_at(A.maps, h.position, A.gather_half_width, A.heavy ? A.heavy_threshold : 0xFFFFFFFFu, inc,
-                                                      inten, gathered, candidates, A.knn_k, KnnColumn{A.knn_ws + i, A.knn_stride});
-                    if (got == 1) surface = material_render_vueon(S, M, h, inc, inten, -d, cnt);
-                    defer = got == 2;  // `once` is written by k_gather_heavy (or below, if the queue is full)
-                }
-                bool deeper = A.level + 1 <= A.max_depth;
-                if (rw > 0.0f && deeper) {
-                    ao = h.position + h.normal * 0.0001f;
-                    ad = norm3(reflect3(h.normal, d));
-                    want_a = true;
-                }
-                if (M.global_part >= 0) {
-                    f3 to, td;
-                    float k;
-                    if (global_refraction(M.parts[M.global_part], h, true, d, to, td, k) && deeper) {
-                        bo = to + td * 0.0001f;
-                        bd = td;
-                        want_b = true;
-                    }
-                }
-                A.cur.once[i] = make_float4(surface.x, surface.y, surface.z, 0.0f);
-                A.cur.glob[i] = make_float4(rw, sw, 0.0f, __uint_as_float(flags));
+            f3 term = mk3(0.0f, 0.0f, 0.0f);
+            if (lit) term = material_per_light(S, M, h, viewer, ldir, cnt) * light_intensity(L, h.position);
+            if (fuse) {
+                if (lit) colour = colour + term;  // scene.rs:116-121, as k_combine adds them
+            } else {
+                A.cur.lights[(size_t)l * A.cur.capacity + i] = make_float4(term.x, term.y, term.z, lit ? 1.0f : 0.0f);
             }
         }
-    }
-
-    // ---- photon mode: file the heavy radiance estimates (one atomic per wave; few waves have any) ----
-    if (MODE == RRT_MODE_PHOTON) {
-        const unsigned long long md = __ballot(defer);
-        if (md) {
-            const uint32_t ln = threadIdx.x & 63u;
-            uint32_t base = 0;
-            if (ln == (uint32_t)__ffsll((long long)md) - 1u) base = atomicAdd(A.heavy_count, (uint32_t)__popcll(md));
-            base = __shfl(base, __ffsll((long long)md) - 1, 64);
-            const uint32_t slot = base + (uint32_t)__popcll(md & (ln == 0 ? 0ULL : (~0ULL >> (64 - ln))));
-            if (defer) {
-                if (slot < A.heavy_capacity) {
-                    HeavyRec R;
-                    R.pos_u = make_float4(h.position.x, h.position.y, h.position.z, h.u);
-                    R.nrm_v = make_float4(h.normal.x, h.normal.y, h.normal.z, h.v);
-                    R.dir_mat = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)h.material));
-                    R.node = i;
-                    R.has_tex = h.has_tex ? 1u : 0u;
-                    R.pad0 = R.pad1 = 0u;
-                    A.heavy[slot] = R;
-                } else {  // queue full: this lane gathers for itself after all
-                    f3 inc, inten;
-                    f3 surface = mk3(0.0f, 0.0f, 0.0f);
-                    if (average_photon_at(A.maps, h.position, A.gather_half_width, 0xFFFFFFFFu, inc, inten, gathered, candidates) == 1)
-                        surface = material_render_vueon(S, S.materials[h.material], h, inc, inten, -d, cnt);
-                    A.cur.once[i] = make_float4(surface.x, surface.y, surface.z, 0.0f);
+        if (fuse) {
+            write_pixel(A, out_pixel, colour, tr.t, tr.object);
+        } else {
+            // the child rays come after the light loop: nothing of them is live across the shadow traversals
+            float wr = 0.0f, wt = 0.0f;
+            if (M.global_part >= 0) {  // GlobalMaterial::compute_once, global_material.rs:71-98
+                const MatPart &G = M.parts[M.global_part];
+                flags |= NF_HAS_GLOBAL;
+                wr = G.wr;
+                wt = G.wt;
+                if (A.level < A.max_depth) {
+                    flags |= NF_GLOBAL_ACTIVE;
+                    if (wr > 0.0f) {
+                        N.ad = norm3(reflect3(h.normal, d));
+                        N.ao = h.position + N.ad * 0.0001f;
+                        N.want_a = true;
+                    }
+                    if (wt > 0.0f) N.want_b = global_refraction(G, h, true, d, N.bo, N.bd, kr);
                 }
             }
+            A.cur.once[i] = make_float4(once.x, once.y, once.z, kr);
+            A.cur.glob[i] = make_float4(wr, wt, div, __uint_as_float(flags));
         }
+    } else {  // PhotonScene::vueontrace, photon_scene.rs:309-361
+        float sw = M.surface_weight, rw = M.w[3];
+        f3 surface = mk3(0.0f, 0.0f, 0.0f);
+        if (sw > 0.0f) {
+            f3 inc, inten;
+            gc.queries += 2;
+            const int got = average_photon_at(A.maps, h.position, A.gather_half_width, A.heavy ? A.heavy_threshold : 0xFFFFFFFFu, inc, inten,
+                                              gc.gathered, gc.candidates, A.knn_k, KnnColumn{A.knn_ws + i, A.knn_stride});
+            if (got == 1) surface = material_render_vueon(S, M, h, inc, inten, -d, cnt);
+            N.defer = got == 2;  // `once` is written by k_gather_heavy (or below, if the queue is full)
+        }
+        bool deeper = A.level + 1 <= A.max_depth;
+        if (rw > 0.0f && deeper) {
+            N.ao = h.position + h.normal * 0.0001f;
+            N.ad = norm3(reflect3(h.normal, d));
+            N.want_a = true;
+        }
+        if (M.global_part >= 0) {
+            f3 to, td;
+            float k;
+            if (global_refraction(M.parts[M.global_part], h, true, d, to, td, k) && deeper) {
+                N.bo = to + td * 0.0001f;
+                N.bd = td;
+                N.want_b = true;
+            }
+        }
+        A.cur.once[i] = make_float4(surface.x, surface.y, surface.z, 0.0f);
+        A.cur.glob[i] = make_float4(rw, sw, 0.0f, __uint_as_float(flags));
     }
+}
 
-    // ---- append of the child rays to the next level's queue, and the statistics: ONE atomic per block each ----
-    // Per wave a 64-bit ballot + lane-prefix popcount gives each lane its slot inside the wave's share; the four waves'
-    // shares are laid end to end through LDS and thread 0 reserves the block's total with a single atomicAdd (one
-    // atomic per wave on the one queue counter serialises in the L2: 32 k waves at 1080p).
+// The block-wide tail of a level's kernel: append of the child rays to the next level's queue and (STATS) the statistics,
+// ONE atomic per block each.  Per wave a 64-bit ballot + lane-prefix popcount gives each lane its slot inside the wave's
+// share; the waves' shares are laid end to end through LDS and thread 0 reserves the block's total with a single atomicAdd
+// (one atomic per wave on the one queue counter serialises in the L2: 32 k waves at 1080p).  Every thread of the block
+// must call it (barriers inside).
+template <int BLOCK, bool STATS>
+__device__ __forceinline__ void finish_block(const TraceArgs &A, uint32_t i, bool write_child, NodeOut &N, const Counters &cnt, const GatherCounts &gc) {
     __shared__ uint32_t s_wave_a[BLOCK / 64], s_wave_b[BLOCK / 64];
     __shared__ uint32_t s_block_base;
     __shared__ unsigned long long s_stat[BLOCK / 64][ST_COUNT];
     __shared__ uint32_t s_err;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
+    unsigned long long ma = __ballot(N.want_a), mb = __ballot(N.want_b);
     uint32_t total = __popcll(ma) + __popcll(mb);
     {
-        unsigned long long v[ST_COUNT] = {cnt.nodes, cnt.tris, cnt.shadow, gathered, queries, candidates};
-#pragma unroll
-        for (int k = 0; k < ST_COUNT; k++) v[k] = wave_sum(v[k]);
         if (threadIdx.x == 0) s_err = 0;
         if (lane == 0) {
             s_wave_a[wave] = __popcll(ma);
             s_wave_b[wave] = __popcll(mb);
+        }
+        if (STATS) {
+#ifdef RRT_WALK_STATS
+            unsigned long long v[ST_COUNT] = {cnt.nodes, cnt.tris, cnt.shadow, A.mode == RRT_MODE_SCENE ? cnt.ws[0] : gc.gathered,
+                                              A.mode == RRT_MODE_SCENE ? cnt.ws[1] : gc.queries, A.mode == RRT_MODE_SCENE ? cnt.ws[2] : gc.candidates};
+#else
+            unsigned long long v[ST_COUNT] = {cnt.nodes, cnt.tris, cnt.shadow, gc.gathered, gc.queries, gc.candidates};
+#endif
 #pragma unroll
-            for (int k = 0; k < ST_COUNT; k++) s_stat[wave][k] = v[k];
+            for (int k = 0; k < ST_COUNT; k++) v[k] = wave_sum(v[k]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < ST_COUNT; k++) s_stat[wave][k] = v[k];
+            }
         }
     }
     __syncthreads();
-    if (cnt.overflow) atomicOr(&s_err, cnt.overflow);
-    if (threadIdx.x < ST_COUNT) {  // thread k owns statistic k
-        unsigned long long sum = 0;
+    if (STATS) {
+        if (cnt.overflow) atomicOr(&s_err, cnt.overflow);
+        if (threadIdx.x < ST_COUNT) {  // thread k owns statistic k
+            unsigned long long sum = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) sum += s_stat[w][threadIdx.x];
-        if (sum) atomicAdd(&A.stats[(blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE + threadIdx.x], sum);
+            for (int w = 0; w < BLOCK / 64; w++) sum += s_stat[w][threadIdx.x];
+            if (sum) atomicAdd(&A.stats[(blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE + threadIdx.x], sum);
+        }
     }
     if (threadIdx.x == 0) {
         uint32_t block_total = 0;
@@ -371,7 +349,7 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
         s_block_base = block_total ? atomicAdd(A.next_count, block_total) : 0u;
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_err) atomicOr(A.err, s_err);
+    if (STATS && threadIdx.x == 0 && s_err) atomicOr(A.err, s_err);
     int2 child = make_int2(-1, -1);
     if (total) {
         // the block's reflection rays first, then its refraction rays: a wave of the next level then holds one kind of
@@ -391,20 +369,100 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
         for (uint32_t w = 0; w < BLOCK / 64; w++) block_end += s_wave_a[w] + s_wave_b[w];
         if (block_end > A.next_limit) {  // prediction too small: the host repeats the frame level by level
             if (lane == 0) atomicOr(A.err, RRT_ERR_BIT_QUEUE);
-            want_a = want_b = false;
+            N.want_a = N.want_b = false;
         }
-        if (want_a) {
+        if (N.want_a) {
             child.x = (int)off_a;
-            A.next.ray_o[off_a] = make_float4(ao.x, ao.y, ao.z, __uint_as_float(i));
-            A.next.ray_d[off_a] = make_float4(ad.x, ad.y, ad.z, __uint_as_float(0u));
+            A.next.ray_o[off_a] = make_float4(N.ao.x, N.ao.y, N.ao.z, __uint_as_float(i));
+            A.next.ray_d[off_a] = make_float4(N.ad.x, N.ad.y, N.ad.z, __uint_as_float(0u));
         }
-        if (want_b) {
+        if (N.want_b) {
             child.y = (int)off_b;
-            A.next.ray_o[off_b] = make_float4(bo.x, bo.y, bo.z, __uint_as_float(i));
-            A.next.ray_d[off_b] = make_float4(bd.x, bd.y, bd.z, __uint_as_float(1u));
+            A.next.ray_o[off_b] = make_float4(N.bo.x, N.bo.y, N.bo.z, __uint_as_float(i));
+            A.next.ray_d[off_b] = make_float4(N.bd.x, N.bd.y, N.bd.z, __uint_as_float(1u));
         }
     }
-    if (active && !(MODE == RRT_MODE_SCENE && FUSE)) A.cur.child[i] = child;
+    if (write_child) A.cur.child[i] = child;
+}
+
+// MODE is a template parameter so that the raytracing-mode instance does not carry the registers of the photon
+// gather and vice versa (occupancy is VGPR-limited here).
+// BLOCK: threads per block, 64 or 256 (launch_trace_shade says which and why).
+// FUSE: single-level frames (TraceArgs.fuse; raytracing mode only): a compile-time constant so that this instance carries
+// neither the child-ray state nor the node arrays' addresses across the shadow traversal.
+template <int MODE, int FEAT, int BLOCK, bool FUSE>
+__global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
+    const DevScene &S = A.S;
+    Lds lds = make_lds(A.S, A.lds_slots, BLOCK);
+    uint32_t block = blockIdx.x;
+    uint32_t i = block * BLOCK + threadIdx.x;
+    uint32_t count = A.count_ptr ? min(*A.count_ptr, A.count) : A.count;
+    bool active = i < count;
+    if (block * BLOCK >= count) return;  // launched for the predicted size of the level
+    Counters cnt = {0, 0, 0, 0};
+    GatherCounts gc;
+    NodeOut N;
+    N.ao = N.ad = N.bo = N.bd = mk3(0, 0, 0);
+    N.h.material = 0;
+    f3 o, d;
+    RRT_WS_STAMP(ws_k0);
+    if (active) {
+        level_ray(A, i, o, d);
+        TraceResult tr;
+        RRT_WS_STAMP(ws_k1);
+        trace<FEAT>(S, o, d, lds, cnt, tr);
+        RRT_WS_STAMP(ws_k2);
+#if RRT_WALK_STATS == 3
+        RRT_WS_ADD(0, ws_k2 - ws_k1);
+#endif
+        shade_node<MODE, FEAT, FUSE>(A, i, o, d, tr, cnt, gc, N, [&](uint32_t, f3 so, f3 sd, float limit) {
+            RRT_WS_STAMP(ws_s0);
+            const bool occ = shadowtrace<FEAT>(S, so, sd, limit, lds, cnt);
+            RRT_WS_STAMP(ws_s1);
+#if RRT_WALK_STATS == 3
+            RRT_WS_ADD(1, ws_s1 - ws_s0);
+#endif
+            return occ;
+        });
+    }
+#if RRT_WALK_STATS == 3
+    {
+        RRT_WS_STAMP(ws_k9);
+        RRT_WS_ADD(2, ws_k9 - ws_k0);  // the whole wave
+    }
+#endif
+
+    // ---- photon mode: file the heavy radiance estimates (one atomic per wave; few waves have any) ----
+    if (MODE == RRT_MODE_PHOTON) {
+        const HitAttr &h = N.h;
+        const unsigned long long md = __ballot(N.defer);
+        if (md) {
+            const uint32_t ln = threadIdx.x & 63u;
+            uint32_t base = 0;
+            if (ln == (uint32_t)__ffsll((long long)md) - 1u) base = atomicAdd(A.heavy_count, (uint32_t)__popcll(md));
+            base = __shfl(base, __ffsll((long long)md) - 1, 64);
+            const uint32_t slot = base + (uint32_t)__popcll(md & (ln == 0 ? 0ULL : (~0ULL >> (64 - ln))));
+            if (N.defer) {
+                if (slot < A.heavy_capacity) {
+                    HeavyRec R;
+                    R.pos_u = make_float4(h.position.x, h.position.y, h.position.z, h.u);
+                    R.nrm_v = make_float4(h.normal.x, h.normal.y, h.normal.z, h.v);
+                    R.dir_mat = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)h.material));
+                    R.node = i;
+                    R.has_tex = h.has_tex ? 1u : 0u;
+                    R.pad0 = R.pad1 = 0u;
+                    A.heavy[slot] = R;
+                } else {  // queue full: this lane gathers for itself after all
+                    f3 inc, inten;
+                    f3 surface = mk3(0.0f, 0.0f, 0.0f);
+                    if (average_photon_at(A.maps, h.position, A.gather_half_width, 0xFFFFFFFFu, inc, inten, gc.gathered, gc.candidates) == 1)
+                        surface = material_render_vueon(S, S.materials[h.material], h, inc, inten, -d, cnt);
+                    A.cur.once[i] = make_float4(surface.x, surface.y, surface.z, 0.0f);
+                }
+            }
+        }
+    }
+    finish_block<BLOCK, true>(A, i, active && !(MODE == RRT_MODE_SCENE && FUSE), N, cnt, gc);
 }
 
 // Photon mode: the radiance estimates the trace kernel filed (HeavyRec), one query per wave.  Grid-stride over the
