@@ -368,6 +368,15 @@ __device__ __forceinline__ void walk_node_step(const MeshView &V, Walk &w, LaneS
     }
 #if RRT_WALK_STATS == 2
     RRT_WS_WAVE_COUNT(0);
+#elif RRT_WALK_STATS == 8  // how often do all the lanes that visit a node visit the SAME node
+    {
+        const unsigned long long m_ = __ballot(true), u_ = __ballot(w.cur == __builtin_amdgcn_readfirstlane(w.cur));
+        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m_) - 1u) {
+            cnt.ws[0] += 1ull;
+            cnt.ws[1] += m_ == u_ ? 1ull : 0ull;
+            cnt.ws[2] += (unsigned long long)__popcll(u_);  // lanes on the first lane's node
+        }
+    }
 #endif
     RRT_WS_TICK(w);  // (inside the loop: a stamp taken on the way out would be sunk behind the loop's exit)
     RRT_WALK_LOG(0u);

@@ -34,6 +34,9 @@ for variant in variants:
         print("  wave time: whole kernel body %d cycles per wave (%d waves); trace() %.1f %%, shadowtrace() %.1f %%" % (c / (W * H / 64), W * H / 64, 100.0 * a / c, 100.0 * b / c))
     elif which == 4:
         print("  wave time: whole kernel body %d cycles per wave; ray set-up %.1f %%, eval_hit %.1f %%" % (c / (W * H / 64), 100.0 * a / c, 100.0 * b / c))
+    elif which == 8:
+        print("  node iterations %d: all active lanes on one node in %.1f %% of them; lanes on the first lane's node per iteration %.1f of %.1f active"
+              % (a, 100.0 * b / max(1, a), c / max(1, a), s["bvh_nodes_visited"] / 4 / max(1, a)))
     elif which == 5:
         nb = int(os.environ.get("RRT_POOL_NB", "8")); pools = W * H / 64 / nb
         print("  pool kernel, cycles per pool of %d batches: rays + other records %d, primary walks %d, shadow set-up (2a) %d" % (nb, a / pools, b / pools, c / pools))
