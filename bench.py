@@ -87,14 +87,32 @@ def cpu_baseline_mesh(rrt, cam, rays_wanted=2304):
     }
 
 
-def measured_counters():
-    """(HBM bytes, VALU lane-operations executed) per k_trace_shade launch of this workload from the committed PMC passes."""
-    f = os.path.join(REPO, "profiles/r02/c4_mesh_pmc_traffic.json")
-    if not os.path.exists(f):
-        return None, None
-    with open(f) as fh:
-        d = json.load(fh)
-    return d.get("hbm_bytes_per_launch"), d.get("valu_lane_ops_executed_per_launch")
+def measured_counters(name="c4_mesh"):
+    """The newest committed PMC summary of a workload (profiles/rNN/<name>_pmc_traffic.json, tools/collect_profiles.py): HBM
+    bytes and VALU lane-operations per launch, together with the kernel time per launch and the git commit they were measured at,
+    so that a bench line can say where its counters come from and drop them when its own kernel no longer takes that long."""
+    for rnd in ("r03", "r02"):
+        rel = "profiles/%s/%s_pmc_traffic.json" % (rnd, name)
+        if os.path.exists(os.path.join(REPO, rel)):
+            with open(os.path.join(REPO, rel)) as fh:
+                d = json.load(fh)
+            d["_path"] = rel
+            return d
+    return None
+
+
+def counters_for(per_launch_ms, name="c4_mesh"):
+    """(traffic, lane_ops, counters_from) for a roofline object: the counters are reported only if the kernel they were collected
+    on ran within 5 % of the time measured now (otherwise the line would mix new timings with old counters)."""
+    d = measured_counters(name)
+    if d is None:
+        return None, None, None
+    then = d.get("kernel_ms_per_launch")
+    src = {"file": d["_path"], "git": d.get("git"), "kernel_ms_per_launch_then": then}
+    if not then or per_launch_ms <= 0 or abs(per_launch_ms - then) / then > 0.05:
+        src["stale"] = "kernel time now %.4f ms: more than 5 %% from the run the counters come from (or unknown); traffic and frac_executed withheld" % per_launch_ms
+        return None, None, src
+    return d.get("hbm_bytes_per_launch"), d.get("valu_lane_ops_executed_per_launch"), src
 
 
 def photon_pass_leg(rrt, torch, D, dist, rank, world, device, stage_host, photons_per_rank, width, height, interleave):
@@ -258,8 +276,8 @@ def main():
     if rank == 0:
         # this rank's launches (its share of every frame): flops of the share / HIP-event time of the share's launches
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        traffic, lane_ops = measured_counters() if world == 1 else (None, None)
         per_launch_ms = kernel_ms / max(1, args.steps)
+        traffic, lane_ops, counters_from = counters_for(per_launch_ms) if world == 1 else (None, None, None)
         gather_bytes = fg.bytes_per_frame()
         out = {
             "metric": "Mrays/s (primary+secondary+shadow rays traced)",
@@ -303,7 +321,8 @@ def main():
                 "valu_lane_ops_executed_per_launch": lane_ops,
                 "frac_executed": lane_ops / (per_launch_ms * 1e-3) / 1e12 / PEAK_FP32_NO_FMA if lane_ops and per_launch_ms > 0 else None,
                 "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, corrected as the MI355X guide prescribes; profiles/r02/c4_mesh_pmc_traffic.json)",
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, corrected as the MI355X guide prescribes), from the committed passes named in counters_from",
+                "counters_from": counters_from,
                 "hbm_gb_per_s": traffic / (per_launch_ms * 1e-3) / 1e9 if traffic and per_launch_ms > 0 else None,
                 "hbm_frac": traffic / (per_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if traffic and per_launch_ms > 0 else None,
                 "kernel_ms_per_launch": per_launch_ms,

@@ -179,7 +179,13 @@ typedef struct rrt_stats {
     uint64_t frames_repeated;    /* render calls since rrt_pre_render that were run twice because a level
                                     queue outgrew the size predicted from the previous frame */
     double ms_bvh_build;         /* rrt_pre_render: time spent building mesh BVHs (host wall clock, whichever builder) */
-    uint64_t reserved[4];
+    /* How often the caps on the reference's unbounded recursions bound (rrt_params.max_photon_bounces, max_vueon_depth;
+     * photon_scene.rs:171-179, 329-352 recurse without limit): photon paths still alive after their last allowed landing
+     * (all rrt_photon_shoot calls since rrt_photon_begin), and reflection / refraction vueons a frame did not trace because they
+     * would have been deeper than the cap (last render call).  0 = the result is what the uncapped recursion gives.       */
+    uint64_t paths_truncated;
+    uint64_t vueons_truncated;
+    uint64_t reserved[2];
 } rrt_stats;
 
 /* ---- builder vtable --------------------------------------------------------------------
@@ -398,8 +404,8 @@ int rrt_photon_save(rrt_scene *s, const char *path);
 int rrt_photon_load(rrt_scene *s, const char *path);
 int rrt_photon_build(rrt_scene *s);
 
-/* rrt_trace for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, results and error behaviour as
+/* rrt_trace for callers that must not call hipMalloc / hipFree: tight serving loops, harnesses that forbid allocation.  (It
+ * works on the null stream and synchronises it twice, so it cannot itself be captured into a HIP graph.)  No counterpart in the reference.  Same arguments, results and error behaviour as
  * rrt_trace (host pointers, any output may be NULL), but every byte of device memory the call needs beyond the scene
  * (staging of the ray and result arrays, the error word, the traversal counters) lives in one static device array of
  * 4.25 MiB that each GPU holds from library load to process exit: the call makes no hipMalloc / hipFree.  At most

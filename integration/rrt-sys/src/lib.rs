@@ -152,7 +152,9 @@ pub struct rrt_stats {
     pub flops_per_trace: u64,
     pub frames_repeated: u64,
     pub ms_bvh_build: f64,
-    pub reserved: [u64; 4],
+    pub paths_truncated: u64,
+    pub vueons_truncated: u64,
+    pub reserved: [u64; 2],
 }
 
 // enum rrt_photon_type

@@ -681,7 +681,7 @@ struct KdTree {
 
 struct Stats {
     std::atomic<uint64_t> rays_primary{0}, rays_secondary{0}, rays_shadow{0}, photons_emitted{0},
-        photons_gathered{0}, gather_queries{0};
+        photons_gathered{0}, gather_queries{0}, paths_truncated{0}, vueons_truncated{0};
     double ms_total = 0, ms_photon_shoot = 0, ms_photon_build = 0;
 };
 
@@ -856,6 +856,8 @@ struct Env {
                 }
             }
         }
+        // the reference recurses on (photon_scene.rs:171-179); the cap of rrt_params.max_photon_bounces cut this path short
+        if (params.max_photon_bounces) stats.paths_truncated.fetch_add(1, std::memory_order_relaxed);
     }
     // point_light.rs:47-148, directional_point_light.rs:58-142: one emitted photon of (light, pass)
     void shoot_one(int li, int pass, uint64_t index, std::vector<Photon> &out) const {
@@ -953,6 +955,7 @@ struct Env {
         if (reflect_weight > 0.0f) {
             V3 ro = hit.position + hit.normal * 0.0001f;
             V3 rd = normalised(reflection(hit.normal, direction));
+            if (depth + 1 > params.max_vueon_depth) stats.vueons_truncated.fetch_add(1, std::memory_order_relaxed);  // photon_scene.rs:329-339 has no cap
             Colour c = (depth + 1 > params.max_vueon_depth) ? black() : vueontrace(ro, rd, depth + 1).colour;
             reflect = c * reflect_weight;
         }
@@ -962,6 +965,7 @@ struct Env {
         float kr;
         if (material->refracted_direction(hit, ray.direction, rr, kr)) {
             V3 ro = rr.position + rr.direction * 0.0001f;
+            if (depth + 1 > params.max_vueon_depth) stats.vueons_truncated.fetch_add(1, std::memory_order_relaxed);
             Colour c = (depth + 1 > params.max_vueon_depth) ? black() : vueontrace(ro, rr.direction, depth + 1).colour;
             refract = c * refract_weight;
         }
@@ -1322,6 +1326,7 @@ int orc_photon_begin(orc_scene *s, uint64_t seed) {
     e.caustic_seeds.assign(e.lights.size(), {});
     e.maps_built = false;
     e.stats.photons_emitted = 0;
+    e.stats.paths_truncated = 0;
     for (auto &l : e.lights)
         if (l.kind == RRT_LIGHT_DIRECTIONAL) return fail(RRT_ERR_INVALID, "Light does not support photon mapping");  // light.rs:16-18
     return RRT_OK;
@@ -1599,6 +1604,8 @@ int orc_get_stats(const orc_scene *s, rrt_stats *out) {
     out->photons_stored_caustic = s->env.local[1].size();
     out->photons_gathered = st.photons_gathered;
     out->gather_queries = st.gather_queries;
+    out->paths_truncated = st.paths_truncated;
+    out->vueons_truncated = st.vueons_truncated;
     return RRT_OK;
 }
 

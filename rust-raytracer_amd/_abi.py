@@ -107,7 +107,9 @@ class Stats(C.Structure):
         ("flops_per_trace", C.c_uint64),
         ("frames_repeated", C.c_uint64),
         ("ms_bvh_build", C.c_double),
-        ("reserved", C.c_uint64 * 4),
+        ("paths_truncated", C.c_uint64),
+        ("vueons_truncated", C.c_uint64),
+        ("reserved", C.c_uint64 * 2),
     ]
 
     def as_dict(self):

@@ -761,6 +761,9 @@ int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_
     lap("kernels (wall)");
     if (timing) fprintf(stderr, "[sah] kernels (HIP events)         %8.2f ms, %u levels, %u nodes\n", ms, levels, total);
     if (word[1] == 1u) return 1;  // non-finite input: the host builder's business
+    // refusals — the node workspace is full (2), a level is wider or the tree deeper than the builder is laid out for (32):
+    // RRT_ERR_LIMIT, which RRT_BVH_AUTO answers with the host builder; everything else is a failed self-check
+    if (word[1] && !(word[1] & ~(2u | 32u))) return fail(RRT_ERR_LIMIT, "device SAH build: workspace or level limit reached");
     if (word[1] || n_inner == 0 || n_inner >= n || total > capacity) {
         char what[160];
         snprintf(what, sizeof(what), "device SAH build produced an invalid tree (internal error): check bits 0x%x, %u inner nodes of %u, %u levels", word[1],

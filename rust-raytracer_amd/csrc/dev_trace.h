@@ -86,6 +86,7 @@ struct LaneStack {
 
 struct Counters {
     uint32_t nodes, tris, shadow, overflow;
+    uint32_t truncated = 0;  // rays or photon paths the recursion caps cut off (rrt_stats.paths_truncated / vueons_truncated)
 #ifdef RRT_WALK_STATS  // instrumentation builds only (tools/walk_stats.sh): three 64-bit sums that travel in the photon statistics' slots
     unsigned long long ws[3] = {0, 0, 0};
 #endif

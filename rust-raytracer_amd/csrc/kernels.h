@@ -47,7 +47,7 @@ struct DevPhotonMap {
 #define RRT_ERR_BIT_QUEUE 8u  // a level queue outgrew the size predicted from the previous frame (internal: retried)
 #define RRT_ERR_BIT_INTERNAL 16u  // a device-side index guard tripped: the kernel refused an out-of-range index
 
-enum StatSlot { ST_NODES = 0, ST_TRIS, ST_SHADOW, ST_GATHERED, ST_QUERIES, ST_CANDIDATES, ST_COUNT };
+enum StatSlot { ST_NODES = 0, ST_TRIS, ST_SHADOW, ST_GATHERED, ST_QUERIES, ST_CANDIDATES, ST_TRUNCATED, ST_COUNT };  // ST_TRUNCATED: see rrt_stats
 // The device-side counters are kept in RRT_STAT_COPIES copies, each on its own 64-byte line, picked by block index, and
 // summed on the host: thousands of waves adding to ONE address serialise in the L2 (measured 4.4 ns per 64-bit atomic,
 // 0.14 ms for the 32 k waves of a 1080p level).

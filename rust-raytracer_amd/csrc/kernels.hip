@@ -277,19 +277,28 @@ __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o,
             if (got == 1) surface = material_render_vueon(S, M, h, inc, inten, -d, cnt);
             N.defer = got == 2;  // `once` is written by k_gather_heavy (or below, if the queue is full)
         }
+        // photon_scene.rs:329-352 recurses without limit; vueons deeper than max_vueon_depth are not traced, and counted
         bool deeper = A.level + 1 <= A.max_depth;
-        if (rw > 0.0f && deeper) {
-            N.ao = h.position + h.normal * 0.0001f;
-            N.ad = norm3(reflect3(h.normal, d));
-            N.want_a = true;
+        if (rw > 0.0f) {
+            if (deeper) {
+                N.ao = h.position + h.normal * 0.0001f;
+                N.ad = norm3(reflect3(h.normal, d));
+                N.want_a = true;
+            } else {
+                cnt.truncated++;
+            }
         }
         if (M.global_part >= 0) {
             f3 to, td;
             float k;
-            if (global_refraction(M.parts[M.global_part], h, true, d, to, td, k) && deeper) {
-                N.bo = to + td * 0.0001f;
-                N.bd = td;
-                N.want_b = true;
+            if (global_refraction(M.parts[M.global_part], h, true, d, to, td, k)) {
+                if (deeper) {
+                    N.bo = to + td * 0.0001f;
+                    N.bd = td;
+                    N.want_b = true;
+                } else {
+                    cnt.truncated++;
+                }
             }
         }
         A.cur.once[i] = make_float4(surface.x, surface.y, surface.z, 0.0f);
@@ -320,9 +329,9 @@ __device__ __forceinline__ void finish_block(const TraceArgs &A, uint32_t i, boo
         if (STATS) {
 #ifdef RRT_WALK_STATS
             unsigned long long v[ST_COUNT] = {cnt.nodes, cnt.tris, cnt.shadow, A.mode == RRT_MODE_SCENE ? cnt.ws[0] : gc.gathered,
-                                              A.mode == RRT_MODE_SCENE ? cnt.ws[1] : gc.queries, A.mode == RRT_MODE_SCENE ? cnt.ws[2] : gc.candidates};
+                                              A.mode == RRT_MODE_SCENE ? cnt.ws[1] : gc.queries, A.mode == RRT_MODE_SCENE ? cnt.ws[2] : gc.candidates, cnt.truncated};
 #else
-            unsigned long long v[ST_COUNT] = {cnt.nodes, cnt.tris, cnt.shadow, gc.gathered, gc.queries, gc.candidates};
+            unsigned long long v[ST_COUNT] = {cnt.nodes, cnt.tris, cnt.shadow, gc.gathered, gc.queries, gc.candidates, cnt.truncated};
 #endif
 #pragma unroll
             for (int k = 0; k < ST_COUNT; k++) v[k] = wave_sum(v[k]);

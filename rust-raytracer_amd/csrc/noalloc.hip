@@ -1,5 +1,5 @@
 // noalloc.hip — rrt_trace_noalloc: the batched Environment::trace (rrt_trace) for callers that cannot allocate device
-// memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+// memory (tight serving loops, harnesses that forbid hipMalloc; not capturable into a HIP graph: it synchronises the null stream).
 //
 // rrt_trace stages its host arrays through device buffers it allocates per call, and keeps its error word and the
 // statistics counters in buffers the scene handle allocated.  Here all of that lives in ONE file-scope device array of a

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_SHOOT_WAVES) void k_photon_shoot(Sho
     const uint32_t n_waves = gridDim.x * (RRT_BLOCK / 64u), wave_id = blockIdx.x * (RRT_BLOCK / 64u) + (threadIdx.x >> 6);
     const uint32_t per_wave = (A.count + n_waves - 1u) / n_waves;
     uint32_t next = (uint32_t)min((uint64_t)wave_id * per_wave, (uint64_t)A.count);
-    const uint32_t end = (uint32_t)min((uint64_t)next + per_wave, (uint64_t)A.count);
+    uint32_t end = (uint32_t)min((uint64_t)next + per_wave, (uint64_t)A.count);
+    if (A.max_bounces == 0) end = next;  // no landing allowed: nothing is traced, nothing stored (as the bounce loop of photontrace would)
     bool alive = false;
     uint32_t bounce = 0;
     Counters cnt = {0, 0, 0, 0};
@@ -297,19 +298,24 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_SHOOT_WAVES) void k_photon_shoot(Sho
             }
         }
         // a photon lands at most max_bounces times (the cap of the reference's unbounded recursion, rrt.h)
-        if (alive && ++bounce >= A.max_bounces) alive = false;
+        if (alive && ++bounce >= A.max_bounces) {
+            alive = false;
+            cnt.truncated++;  // the reference would have traced on (photon_scene.rs:171-179): rrt_stats.paths_truncated
+        }
       }
     }
-    unsigned long long n = cnt.nodes, t = cnt.tris;
+    unsigned long long n = cnt.nodes, t = cnt.tris, cut = cnt.truncated;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         n += __shfl_xor(n, off, 64);
         t += __shfl_xor(t, off, 64);
+        cut += __shfl_xor(cut, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         unsigned long long *stats = A.stats + (blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE;
         if (n) atomicAdd(&stats[ST_NODES], n);
         if (t) atomicAdd(&stats[ST_TRIS], t);
+        if (cut) atomicAdd(&stats[ST_TRUNCATED], cut);
     }
     err |= cnt.overflow;
     if (err) atomicOr(A.err, err);
@@ -770,6 +776,7 @@ int rrt_photon_begin(rrt_scene *s, uint64_t seed) {
     s->seeds.clear();
     for (size_t i = 0; i < s->lights.size(); i++) s->seeds.push_back(std::make_unique<CausticSeeds>());
     s->stats.photons_emitted = 0;
+    s->stats.paths_truncated = 0;
     s->stats.ms_photon_shoot = 0;
     s->stats.ms_photon_build = 0;
     return RRT_OK;
@@ -893,6 +900,7 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
         if ((rc = read_stats(s, st))) return rc;
         s->stats.bvh_nodes_visited = st[ST_NODES];
         s->stats.bvh_tris_tested = st[ST_TRIS];
+        s->stats.paths_truncated += st[ST_TRUNCATED];
         if (pass == 0) {
             // photon_scene.rs:48-57: the Caustic-tagged records of pass 1 are what pass 2 aims at.  Everything
             // this call appended to the caustic buffer is Caustic-tagged; merge with earlier ranges.
@@ -1173,7 +1181,8 @@ int rrt_photon_nearest(rrt_scene *s, int which, const float *positions, size_t n
 }
 
 // ---- photon-map files (keep the maps between runs, re-render without re-shooting) ----
-// Layout, little endian: "RRTPMAP1", u32 version (1), u32 bytes per record (56), u64 seed, u64 count[2], then per map
+// Layout, little endian: "RRTPMAP1", u32 version (2: record keys are index * 65536 + landing * 1024 + sub-index; version 1 files
+// of round 1 keyed index * 4096 + landing * 64 + sub-index and are refused), u32 bytes per record (56), u64 seed, u64 count[2], then per map
 // pos[count] float4 (w = type), incident[count] float4, intensity[count] float4, meta[count] u64, in canonical order.
 namespace {
 struct PmapHeader {
@@ -1195,7 +1204,7 @@ int rrt_photon_save(rrt_scene *s, const char *path) {
     if (!f) return fail(RRT_ERR_IO, std::string("cannot write ") + path);
     PmapHeader h;
     memcpy(h.magic, "RRTPMAP1", 8);
-    h.version = 1;
+    h.version = 2;
     h.record_bytes = 56;
     h.seed = s->seed;
     h.count[0] = s->local[0].count;
@@ -1229,9 +1238,9 @@ int rrt_photon_load(rrt_scene *s, const char *path) {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(RRT_ERR_IO, std::string("cannot open ") + path);
     PmapHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RRTPMAP1", 8) != 0 || h.version != 1 || h.record_bytes != 56) {
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RRTPMAP1", 8) != 0 || h.version != 2 || h.record_bytes != 56) {
         fclose(f);
-        return fail(RRT_ERR_PARSE, std::string(path) + " is not a photon-map file of this build (RRTPMAP1, version 1)");
+        return fail(RRT_ERR_PARSE, std::string(path) + " is not a photon-map file of this build (RRTPMAP1, version 2; version 1 files carry another key layout)");
     }
     if (h.count[0] >= (1ull << 32) || h.count[1] >= (1ull << 32)) {
         fclose(f);

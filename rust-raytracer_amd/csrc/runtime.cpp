@@ -240,6 +240,11 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
             break;
         }
         case RRT_OBJ_MESH: {
+            // a leaf code holds its first triangle slot in 27 bits (BvhNodeQ, bvh_build.cpp), whichever builder made the tree
+            if (o.tri_pos.size() / 9 >= (1u << 27)) {
+                if (!F.error) F.error = fail(RRT_ERR_LIMIT, "a mesh with 2^27 or more triangles");
+                break;
+            }
             uint32_t n = (uint32_t)(o.tri_pos.size() / 9);
             MeshInfo mi;
             mi.tri_first = (uint32_t)F.tris.size();
@@ -263,7 +268,8 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
                 built = rc != 1;  // 1: a coordinate is not finite: the host builder and its "wild mesh" rules take the mesh
                 // RRT_BVH_AUTO promises a tree, not a device build: whatever the device builder refuses (its workspace does not
                 // fit, a tree deeper than its level limit) goes to the host builder, which makes the same tree
-                if (rc < 0 && F.bvh_builder == RRT_BVH_AUTO) built = false;
+                // (RRT_ERR_LIMIT only: a HIP error or a failed self-check of the device builder is reported, not papered over)
+                if (rc == RRT_ERR_LIMIT && F.bvh_builder == RRT_BVH_AUTO) built = false;
                 if (!built) rc = RRT_OK;
             }
             if (rc) {
@@ -1000,6 +1006,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
     O.photons_gathered = st[ST_GATHERED];
     O.gather_queries = st[ST_QUERIES];
     O.gather_candidates = st[ST_CANDIDATES];
+    O.vueons_truncated = s->mode == RRT_MODE_PHOTON ? st[ST_TRUNCATED] : 0;
     O.flops_per_trace = D.flops_per_trace;
     O.flops_algorithmic = (O.rays_primary + O.rays_secondary + O.rays_shadow) * D.flops_per_trace + 27ull * st[ST_NODES] + 61ull * st[ST_TRIS];
     O.ms_trace_kernels = R.ms_trace;
@@ -1076,6 +1083,7 @@ void copy_render_stats(rrt_stats &to, const rrt_stats &from) {
     to.photons_gathered = from.photons_gathered;
     to.gather_queries = from.gather_queries;
     to.gather_candidates = from.gather_candidates;
+    to.vueons_truncated = from.vueons_truncated;
     to.flops_per_trace = from.flops_per_trace;
     to.flops_algorithmic = from.flops_algorithmic;
     to.ms_trace_kernels = from.ms_trace_kernels;

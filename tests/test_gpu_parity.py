@@ -440,6 +440,25 @@ def test_full_size_frame_properties(repo):
     assert np.array_equal(r_ids, ids[540]) and np.array_equal(bits(r_depth), bits(depth[540])) and np.array_equal(bits(r_rgb), bits(rgb[540]))
 
 
+def test_scene2_raytracing_mode_at_its_full_size(repo):
+    """BASELINE configs[0]: assets/scenes/scene2.txt in raytracing mode at its own 1024 x 1024 (the committed file selects
+    PhotonScene: the mode is overridden).  The whole frame through the oracle: object ids and depth buffer
+    the same bits, RGB within 1/255, the same numbers of rays; and the depth buffer quantises to the reference's committed
+    render/depth.ppm (every byte 255: a weak check, but the only stored output of the depth path)."""
+    cpu, gpu, cam = load_pair(repo, "scene2")
+    assert (cam.width, cam.height) == (1024, 1024)
+    gpu.pre_render(1)
+    rgb_g, depth_g, id_g = gpu.render(cam)
+    rgb_c, depth_c, id_c = cpu.render(cam)
+    assert np.array_equal(id_g, id_c) and np.array_equal(bits(depth_g), bits(depth_c))
+    assert np.abs(rrt.quantise(rgb_g).astype(int) - ob.quantise(rgb_c).astype(int)).max() <= 1
+    sg, sc = gpu.stats(), cpu.stats()
+    for k in ("rays_primary", "rays_secondary", "rays_shadow"):
+        assert sg[k] == sc[k], k
+    golden = open(os.path.join(repo, "tests/golden/render/depth.ppm"), "rb").read()
+    assert rrt.quantise(depth_g).tobytes() == golden[-1024 * 1024:]
+
+
 def test_render_rejects_bad_input(repo):
     gpu, cam = rrt.Scene.load(os.path.join(repo, "assets/scenes/quadratics.txt"))
     with pytest.raises(rrt.RrtError) as e:

@@ -403,3 +403,96 @@ def test_more_than_63_shadow_photons_behind_one_landing(repo):
         assert np.array_equal(bits(pc[k]), bits(pg[k])), k
     sub = pg["key"] & np.uint64(1023)
     assert sub.max() >= 80, sub.max()          # far more than the 63 the old layout could name
+
+
+@pytest.mark.parametrize("name,photons,caustic", [("pm_caustics", 40000, 3000), ("scene2", 120000, 5000), ("pm_diffuse", 30000, 1000), ("scene", 30000, 1000),
+                                                  ("textures", 20000, 500), ("reflection_refraction", 20000, 500), ("quadratics", 20000, 500)])
+def test_recursion_caps_do_not_bind_on_the_reference_scenes(repo, name, photons, caustic):
+    """photon_scene.rs:171-179 and :329-352 recurse without limit; product and oracle cap at max_photon_bounces landings and
+    max_vueon_depth levels (rrt_params).  Both sides count how often a cap cut something off: the counts agree, and on the
+    reference's own seven scenes (each forced into photon mode) they are ZERO at the default caps, i.e. the caps change nothing
+    there.  With tight caps the counters move, on both sides alike."""
+    path = os.path.join(repo, "assets/scenes", name + ".txt")
+    for tight in (False, True):
+        more = dict(max_photon_bounces=2, max_vueon_depth=0) if tight else {}
+        params = rrt.default_params(photons_per_light=photons, caustic_photons_per_light=caustic, **more)
+        cpu, cam = ob.OracleScene.load(path, params=params, mode_override=abi.MODE_PHOTON)
+        gpu, _ = rrt.Scene.load(path, params=params, mode_override=abi.MODE_PHOTON)
+        try:
+            cpu.pre_render(3)
+        except ob.OracleError as e:   # a Directional light cannot shoot photons (light.rs:16-18): both sides refuse the scene
+            assert "does not support photon mapping" in str(e)
+            with pytest.raises(rrt.RrtError):
+                gpu.pre_render(3)
+            return
+        gpu.pre_render(3)
+        cam.width, cam.height = 128, 96
+        cpu.render(cam)
+        gpu.render(cam)
+        sc, sg = cpu.stats(), gpu.stats()
+        assert sg["paths_truncated"] == sc["paths_truncated"] and sg["vueons_truncated"] == sc["vueons_truncated"], (name, tight, sg, sc)
+        if not tight:
+            assert sg["paths_truncated"] == 0 and sg["vueons_truncated"] == 0, (name, sg["paths_truncated"], sg["vueons_truncated"])
+        elif name in ("pm_caustics", "scene2", "scene"):   # glass and mirrors in view: vueons wanted behind level 0
+            assert sg["paths_truncated"] > 0 and sg["vueons_truncated"] > 0
+
+
+@pytest.mark.parametrize("bounces", [0, 1, 2])
+def test_photon_bounce_cap_of_zero_and_one(repo, bounces):
+    """max_photon_bounces = 0 stores nothing (the bounce loop of photontrace never runs), 1 stores every photon's first landing and its
+    shadow photons: both maps as the oracle's, record for record."""
+    cpu, gpu, cam = pair(repo, "pm_caustics", 20000, 1000, max_photon_bounces=bounces)
+    cpu.pre_render(5)
+    gpu.pre_render(5)
+    for which in (0, 1):
+        pc, pg = cpu.photon_read(which), gpu.photon_read(which)
+        assert np.array_equal(pc["key"], pg["key"]) and np.array_equal(pc["type"], pg["type"])
+        for k in ("position", "incident", "intensity"):
+            assert np.array_equal(bits(pc[k]), bits(pg[k])), (which, k)
+    n = len(gpu.photon_read(0)["key"]) + len(gpu.photon_read(1)["key"])
+    assert (n == 0) == (bounces == 0)
+    assert gpu.stats()["paths_truncated"] == cpu.stats()["paths_truncated"]
+    if bounces == 1:
+        assert (gpu.photon_read(0)["key"] >> 10 & 63).max() == 0   # landing number 0 only
+
+
+def two_light_scene(scene):
+    """A floor, a back wall, a matt sphere and a glass sphere under a Point light AND a DirPoint light: the reference shoots the lights
+    one after the other and concatenates their photons (photon_scene.rs:98-148); keys carry (light * 2 + pass) << 56."""
+    import scene_kit as kit
+    floor = kit.monochrome(scene, (0.6, 0.6, 0.6), 0.1, 50.0)
+    wall = kit.monochrome(scene, (0.3, 0.4, 0.8), 0.1, 50.0)
+    matt = kit.monochrome(scene, (0.8, 0.3, 0.2), 0.1, 20.0)
+    t = 0.8
+    glass = kit.compound(scene, [kit.monochrome(scene, (0.9 * (1 - t), 0.9 * (1 - t), 0.9 * (1 - t)), 0.1, 100.0), kit.global_material(scene, t, t, 1.5)])
+    scene.add_object(kit.plane(scene, (0, -1, 0), (0, 0, 1), (0, 1, 0), floor))
+    scene.add_object(kit.plane(scene, (0, 0, 8), (0, 1, 0), (0, 0, -1), wall))
+    scene.add_object(kit.sphere(scene, (-1.5, 0.0, 5.0), 1.0, matt))
+    scene.add_object(kit.sphere(scene, (1.2, 0.3, 4.0), 0.9, glass))
+    kit.light(scene, abi.LIGHT_POINT, position=(2.0, 4.0, 2.0), colour=(0.9, 0.8, 0.7))
+    kit.light(scene, abi.LIGHT_DIRPOINT, position=(-3.0, 5.0, 3.0), direction=(0.4, -1.0, 0.2), colour=(0.5, 0.6, 0.9))
+    return scene
+
+
+def test_two_lights_in_photon_mode(repo):
+    params = rrt.default_params(photons_per_light=30000, caustic_photons_per_light=2000)
+    cpu = two_light_scene(ob.OracleScene(abi.MODE_PHOTON, params))
+    gpu = two_light_scene(rrt.Scene(abi.MODE_PHOTON, params))
+    cpu.pre_render(11)
+    gpu.pre_render(11)
+    for which in (0, 1):
+        pc, pg = cpu.photon_read(which), gpu.photon_read(which)
+        assert np.array_equal(pc["key"], pg["key"]) and np.array_equal(pc["type"], pg["type"])
+        for k in ("position", "incident", "intensity"):
+            assert np.array_equal(bits(pc[k]), bits(pg[k])), (which, k)
+        tags = np.unique(pg["key"] >> 56)
+        # regular map: pass 0 of both lights; caustic map: pass-0 caustic photons and everything of pass 1, of both lights
+        assert set(tags.tolist()) == ({0, 2} if which == 0 else {0, 1, 2, 3}), (which, tags)
+    assert gpu.stats()["photons_emitted"] == 2 * (30000 + 2000)
+    cam = rrt.make_camera(160, 120, 0.7, (0.0, 0.5, -3.0), (0.0, 0.0, 1.0))
+    rgb_c, depth_c, id_c = cpu.render(cam)
+    rgb_g, depth_g, id_g = gpu.render(cam)
+    assert np.array_equal(id_c, id_g) and np.array_equal(bits(depth_c), bits(depth_g))
+    dq = np.abs(ob.quantise(rgb_c).astype(int) - rrt.quantise(rgb_g).astype(int))
+    assert dq.mean() < 0.05 and (dq > 1).mean() < 1e-3, (dq.mean(), dq.max())
+    assert gpu.stats()["photons_gathered"] == cpu.stats()["photons_gathered"]

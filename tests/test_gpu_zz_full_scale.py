@@ -65,20 +65,61 @@ def test_c4_million_triangle_mesh_4k_both_builders_and_oracle_sample(repo):
     assert (ids == 0).mean() > 0.1 and (ids == 1).mean() > 0.05          # teapots and floor both in view
     top, bottom = scenes[1].render(cam, 0, 1000), scenes[1].render(cam, 1000, 2160)
     assert np.array_equal(bits(np.concatenate([top[0], bottom[0]])), bits(rgb))
-    # oracle sample: camera rays of random pixels, brute force over every triangle
+    # oracle sample: 4096 camera rays — a third on teapot silhouettes (pixels whose neighbour shows another object), a third on
+    # the teapots, the rest anywhere — and the shadow rays of their hits, all through the oracle's brute force over every triangle
     rng = np.random.default_rng(4)
-    px = np.stack([rng.integers(0, 3840, 96), rng.integers(0, 2160, 96)], axis=1)
+    edge = np.zeros(ids.shape, bool)
+    edge[:, 1:] |= ids[:, 1:] != ids[:, :-1]
+    edge[1:, :] |= ids[1:, :] != ids[:-1, :]
+    on_edge, on_mesh = np.argwhere(edge), np.argwhere(ids == 0)
+    assert len(on_edge) > 10000
+    px = np.concatenate([on_edge[rng.choice(len(on_edge), 1400, replace=False)][:, ::-1], on_mesh[rng.choice(len(on_mesh), 1400, replace=False)][:, ::-1],
+                         np.stack([rng.integers(0, 3840, 1296), rng.integers(0, 2160, 1296)], axis=1)])
     rays = [rrt.camera_ray(cam, int(x), int(y)) for x, y in px]
-    o = np.array([r[0] for r in rays], np.float32)
-    d = np.array([r[1] for r in rays], np.float32)
+    o = np.ascontiguousarray([r[0] for r in rays], np.float32)
+    d = np.ascontiguousarray([r[1] for r in rays], np.float32)
     cpu = build(ob.OracleScene())
-    c = cpu.trace(o, d)
+    cpu.pre_render(1, threads=1)
+    c = threaded(lambda idx: cpu.trace(o[idx], d[idx]), len(o))
     for s in scenes:
         g = s.trace(o, d)
         for k in ("object_id", "prim_id", "distance", "position", "normal"):
             assert np.array_equal(bits(g[k]), bits(c[k])), k
     assert np.array_equal(c["object_id"], ids[px[:, 1], px[:, 0]])       # and they are the frame's primary hits
     assert np.array_equal(bits(c["distance"]), bits(depth[px[:, 1], px[:, 0]]))
+    # Scene::shadowtrace from every hit towards the light, limit |ldir| = 1 (scene.rs:106-111): grazing rays that start ON the mesh
+    hit = c["object_id"] != 0xFFFFFFFF
+    pos = c["position"][hit]
+    ldir = pos - np.array([0.0, 400.0, -300.0], np.float32)
+    ldir = (ldir / np.sqrt((ldir * ldir).sum(axis=1, dtype=np.float32))[:, None]).astype(np.float32)
+    sd = -ldir
+    so = (pos + sd * np.float32(0.0001)).astype(np.float32)
+    limits = np.ones(len(so), np.float32)
+    occ_c = threaded(lambda idx: {"o": cpu.shadowtrace(so[idx], sd[idx], limits[idx])}, len(so))["o"]
+    assert 0.02 < occ_c.mean() < 0.9                                      # some hits are in shadow, some are lit
+    for s in scenes:
+        assert np.array_equal(s.shadowtrace(so, sd, limits), occ_c)
+
+
+def threaded(fn, n, threads=None):
+    """fn(index array) -> dict of arrays, over min(16, cpus) host threads (the oracle's calls release the GIL); results concatenated"""
+    import threading
+
+    import numpy as np
+
+    threads = threads or min(16, os.cpu_count() or 1)
+    parts = [p for p in np.array_split(np.arange(n), threads) if len(p)]
+    out = [None] * len(parts)
+
+    def work(j):
+        out[j] = fn(parts[j])
+
+    th = [threading.Thread(target=work, args=(j,)) for j in range(len(parts))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return {k: np.concatenate([p[k] for p in out]) for k in out[0]}
 
 
 @pytest.mark.parametrize("variant", ["mirror", "glass"])
@@ -88,7 +129,6 @@ def test_c4_secondary_rays_through_the_million_triangle_bvh(repo, variant):
     sample of the 4K frame's camera rays goes through the oracle (brute force over every triangle for every bounce and
     shadow ray): object ids and depth bit-exact, RGB within 1/255; and the sample equals the frame's pixels."""
     import sys
-    import threading
 
     import numpy as np
 
@@ -109,25 +149,19 @@ def test_c4_secondary_rays_through_the_million_triangle_bvh(repo, variant):
     bench_extra.build_mesh_scene(rrt, variant=variant, scene=cpu)
     cpu.pre_render(1, threads=1)
     rng = np.random.default_rng(11)
-    # pixels on teapots (object 0) are the ones that spawn secondary rays: take most of the sample there
-    on_mesh = np.argwhere(ids == 0)
-    pick = on_mesh[rng.choice(len(on_mesh), 72, replace=False)]
-    px = np.concatenate([pick[:, ::-1], np.stack([rng.integers(0, 3840, 24), rng.integers(0, 2160, 24)], axis=1)])
+    # 1024 rays: pixels on teapots (object 0) are the ones that spawn secondary rays, so most of the sample lies there, a third of
+    # it on silhouettes (pixels whose neighbour shows another object), the rest anywhere
+    edge = np.zeros(ids.shape, bool)
+    edge[:, 1:] |= ids[:, 1:] != ids[:, :-1]
+    edge[1:, :] |= ids[1:, :] != ids[:-1, :]
+    on_edge, on_mesh = np.argwhere(edge), np.argwhere(ids == 0)
+    px = np.concatenate([on_edge[rng.choice(len(on_edge), 340, replace=False)][:, ::-1], on_mesh[rng.choice(len(on_mesh), 500, replace=False)][:, ::-1],
+                         np.stack([rng.integers(0, 3840, 184), rng.integers(0, 2160, 184)], axis=1)])
     rays = [rrt.camera_ray(cam, int(x), int(y)) for x, y in px]
     o = np.ascontiguousarray([r[0] for r in rays], np.float32)
     d = np.ascontiguousarray([r[1] for r in rays], np.float32)
-    n_threads = min(8, os.cpu_count() or 1)
-    parts, out = np.array_split(np.arange(len(o)), n_threads), [None] * n_threads
-
-    def work(j):
-        out[j] = cpu.raytrace(o[parts[j]], d[parts[j]])
-
-    th = [threading.Thread(target=work, args=(j,)) for j in range(n_threads)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    rgb_c, depth_c, id_c = (np.concatenate([p[k] for p in out]) for k in range(3))
+    res = threaded(lambda idx: dict(zip(("rgb", "depth", "id"), cpu.raytrace(o[idx], d[idx]))), len(o))
+    rgb_c, depth_c, id_c = res["rgb"], res["depth"], res["id"]
     rgb_g, depth_g, id_g = gpu.raytrace(o, d)
     assert np.array_equal(id_g, id_c) and np.array_equal(bits(depth_g), bits(depth_c))
     assert np.abs(rrt.quantise(rgb_g).astype(int) - ob.quantise(rgb_c).astype(int)).max() <= 1
