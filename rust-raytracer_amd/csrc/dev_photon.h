@@ -138,7 +138,9 @@ __device__ __forceinline__ DenseBox dense_box(const DenseGrid &D, float inv_dcel
 }
 // the grid a position is filed in (the first whose box holds it) and its cell there; false: an outlier
 RRT_HD bool dense_cell_of(const DevPhotonMap &G, float x, float y, float z, uint32_t &cell) {
-    for (uint32_t g = 0; g < G.n_grids; g++) {
+#pragma unroll
+    for (uint32_t g = 0; g < RRT_DENSE_GRIDS; g++) {  // (constant indices into the argument block: see fine_box)
+        if (g >= G.n_grids) break;
         const DenseGrid &D = G.grid[g];
         const float fx = dense_coord(x, D.lo_x, G.inv_dcell), fy = dense_coord(y, D.lo_y, G.inv_dcell), fz = dense_coord(z, D.lo_z, G.inv_dcell);
         if (fx >= 0.0f && fx < (float)D.nx && fy >= 0.0f && fy < (float)D.ny && fz >= 0.0f && fz < (float)D.nz) {
@@ -193,7 +195,9 @@ __device__ __forceinline__ void visit_outlier_cells(const DevPhotonMap &G, f3 lo
 template <class F>
 __device__ __forceinline__ void visit_runs(const DevPhotonMap &G, f3 lo, f3 hi, F &&f) {
     if (G.count == 0) return;
-    for (uint32_t g = 0; g < G.n_grids; g++) {
+#pragma unroll
+    for (uint32_t g = 0; g < RRT_DENSE_GRIDS; g++) {  // (constant indices into the argument block: see fine_box)
+        if (g >= G.n_grids) break;
         const DenseGrid &D = G.grid[g];
         const DenseBox B = dense_box(D, G.inv_dcell, lo, hi);
         if (!B.empty)
@@ -227,7 +231,9 @@ __device__ __forceinline__ bool lookup_cells(const DevPhotonMap &G, f3 lo, f3 hi
 #pragma unroll
     for (uint32_t c = 0; c < 9; c++) C.rg[c] = make_uint2(0, 0);
     if (G.count == 0) return true;
-    for (uint32_t g = 0; g < G.n_grids; g++) {
+#pragma unroll
+    for (uint32_t g = 0; g < RRT_DENSE_GRIDS; g++) {  // (constant indices into the argument block: see fine_box)
+        if (g >= G.n_grids) break;
         const DenseGrid &D = G.grid[g];
         const DenseBox B = dense_box(D, G.inv_dcell, lo, hi);
         if (B.empty) continue;           // nothing of the box in this grid: the next one
@@ -250,6 +256,91 @@ __device__ __forceinline__ void stream_cells(const DevPhotonMap &G, const CellSe
     s.candidates = 0;
 #pragma unroll
     for (uint32_t c = 0; c < 9; c++) stream_cell(G, C.rg[c], lo, hi, s);
+}
+
+// ---- fine grids (DevPhotonMap::div > 1): cells of edge r / div and per-cell sums ------------------------------------
+// In a crowded map (tens of millions of records) a query cube holds thousands of photons and neighbouring pixels stream
+// nearly the same ones.  With cells of edge r / div the cube spans 2 div + 1 (or + 2) cells along each axis, and every cell
+// STRICTLY between the cube's first and last cell along all three axes lies wholly inside the closed cube: dense_coord is
+// monotone in x, so a record whose cell coordinate is above that of the cube's lower bound is itself above the bound, and
+// the same at the upper bound — exactly, in float arithmetic.  Such cells are not streamed: the index keeps per cell the
+// sums the estimate needs (normalised incidents, intensities, in canonical order; the count is the start table's), and the
+// query adds those.  Only the cube's shell is read record by record.  Same photon SET as the reference's box query
+// (photon_tree.rs:15-35), counts exact; the f32 sums are grouped by cell, i.e. differ by rounding only.
+// Used when the cube lies wholly inside a grid's box (as the coarse fast path); anything else takes the general walk.
+struct FineBox {
+    DenseBox B;
+    uint32_t cell_base, nx, ny;  // of the grid that holds the cube
+    bool any;  // false: the cube meets no dense grid (and the map has no outliers): nothing to gather
+};
+__device__ __forceinline__ bool fine_box(const DevPhotonMap &G, f3 lo, f3 hi, FineBox &F) {
+    F.any = false;
+    F.cell_base = F.nx = F.ny = 0;
+    if (G.count == 0) return true;
+    // (unrolled: an index into the kernel's argument block that is not a constant makes the compiler copy the block to scratch)
+#pragma unroll
+    for (uint32_t g = 0; g < RRT_DENSE_GRIDS; g++) {
+        if (g >= G.n_grids) break;
+        const DenseGrid &D = G.grid[g];
+        const DenseBox B = dense_box(D, G.inv_dcell, lo, hi);
+        if (B.empty) continue;        // nothing of the cube in this grid: the next one
+        if (B.outside) return false;  // partly in this grid: the general walk
+        F.B = B;
+        F.cell_base = D.cell_base, F.nx = D.nx, F.ny = D.ny;
+        F.any = true;
+        return true;
+    }
+    return G.n_dense == G.count;  // outside every grid: only outliers can be there, if there are any
+}
+// rows (y, z) of the box: `stream(first, count)` for runs of records to be tested one by one, `whole(first_cell, last_cell,
+// count)` for runs of cells that lie inside the cube as a whole
+template <class Stream, class Whole>
+__device__ __forceinline__ void visit_fine(const DevPhotonMap &G, const FineBox &F, Stream &&stream, Whole &&whole) {
+    if (!F.any) return;
+    const DenseBox &B = F.B;
+    const bool x_inner = B.x1 - B.x0 >= 2;
+    for (int z = B.z0; z <= B.z1; z++)
+        for (int y = B.y0; y <= B.y1; y++) {
+            const uint32_t row = F.cell_base + ((uint32_t)z * F.ny + (uint32_t)y) * F.nx;
+            // the row's records are one run [a, d); on an inner row its middle [b, c) is whole cells
+            const uint32_t a = G.dense_start[row + (uint32_t)B.x0], d = G.dense_start[row + (uint32_t)B.x1 + 1u];
+            uint32_t b = d, c = d;
+            if (x_inner && z > B.z0 && z < B.z1 && y > B.y0 && y < B.y1) {
+                b = G.dense_start[row + (uint32_t)B.x0 + 1u];
+                c = G.dense_start[row + (uint32_t)B.x1];
+                if (c != b) whole(row + (uint32_t)B.x0 + 1u, row + (uint32_t)B.x1 - 1u, c - b);
+            }
+            // (one call site, so that the streaming loop exists once in the code)
+#pragma clang loop unroll(disable)
+            for (int part = 0; part < 2; part++) stream(part ? c : a, part ? d - c : b - a);
+        }
+}
+// records the shell of the cube holds (what a lane would read): the heavy-query decision, before any record is read
+__device__ __forceinline__ uint32_t fine_candidates(const DevPhotonMap &G, const FineBox &F) {
+    uint32_t n = 0;
+    visit_fine(G, F, [&](uint32_t, uint32_t count) { n += count; }, [&](uint32_t, uint32_t, uint32_t) {});
+    return n;
+}
+__device__ __forceinline__ void add_cells(const DevPhotonMap &G, uint32_t first_cell, uint32_t last_cell, GatherSums &s) {
+    for (uint32_t c = first_cell; c <= last_cell; c++) {
+        const float4 d = G.agg_dir[c];
+        if (__float_as_uint(d.w) == 0u) continue;  // (w = records of the cell)
+        const float4 i = G.agg_rgb[c];
+        s.ldir = s.ldir + mk3(d.x, d.y, d.z);
+        s.intensity = s.intensity + mk3(i.x, i.y, i.z);
+    }
+}
+__device__ __forceinline__ void gather_fine(const DevPhotonMap &G, const FineBox &F, f3 lo, f3 hi, GatherSums &s) {
+    s.ldir = mk3(0.0f, 0.0f, 0.0f);
+    s.intensity = mk3(0.0f, 0.0f, 0.0f);
+    s.k = 0;
+    s.candidates = 0;
+    visit_fine(
+        G, F, [&](uint32_t first, uint32_t count) { stream_cell(G, make_uint2(first, count), lo, hi, s); },
+        [&](uint32_t first_cell, uint32_t last_cell, uint32_t count) {
+            add_cells(G, first_cell, last_cell, s);
+            s.k += count;
+        });
 }
 
 // ---- PhotonTree::get_n_within_radius (photon_tree.rs:41-50) as the estimator ------------------------------------------
@@ -363,6 +454,9 @@ __device__ __forceinline__ bool blend_estimates(const GatherSums &reg, const Gat
 // average_photon_at (photon_scene.rs:363-420): regular and caustic estimates and their blend.
 // Returns 0: no photons, 1: estimate in (incident, intensity), 2: DEFERRED -- the two boxes hold more than `defer_above`
 // candidate records, nothing was read, the caller files the query for k_gather_heavy (pass 0xFFFFFFFF to never defer).
+// FINE: the maps are fine grids (DevPhotonMap::div > 1; both maps of a scene are built alike): an instance of its own, so
+// that the coarse path keeps its registers.
+template <bool FINE>
 __device__ __forceinline__ int average_photon_at(const DevPhotonMap maps[2], f3 p, float r, uint32_t defer_above, f3 &incident, f3 &intensity,
                                                  unsigned long long &gathered, unsigned long long &candidates, uint32_t knn_k = 0,
                                                  KnnColumn knn = KnnColumn{nullptr, 0}) {
@@ -375,6 +469,24 @@ __device__ __forceinline__ int average_photon_at(const DevPhotonMap maps[2], f3 
         return blend_estimates(reg, cau, incident, intensity) ? 1 : 0;
     }
     f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);  // photon_tree.rs:16-18
+    if (FINE) {
+        FineBox f;
+        uint32_t shell = 0;  // records a lane would read: the heavy-query decision, before any of them is read
+        if (fine_box(maps[0], lo, hi, f)) shell += fine_candidates(maps[0], f);
+        if (fine_box(maps[1], lo, hi, f)) shell += fine_candidates(maps[1], f);
+        if (shell > defer_above) return 2;
+        if (fine_box(maps[0], lo, hi, f))
+            gather_fine(maps[0], f, lo, hi, reg);
+        else
+            gather_box(maps[0], p, r, reg);
+        if (fine_box(maps[1], lo, hi, f))
+            gather_fine(maps[1], f, lo, hi, cau);
+        else
+            gather_box(maps[1], p, r, cau);
+        gathered += reg.k + cau.k;
+        candidates += reg.candidates + cau.candidates;
+        return blend_estimates(reg, cau, incident, intensity) ? 1 : 0;
+    }
     // Each map on its own: the common case is a box inside one dense grid (9 runs, known before a record is read); a box
     // that straddles grid boxes or may hold outliers takes the general walk FOR THAT MAP only (the caustic map is small
     // and most queries fall outside its grids: that must not push the regular map's lookup onto the slow path as well).
@@ -428,6 +540,42 @@ __device__ __forceinline__ void wave_gather_box(const DevPhotonMap &G, f3 p, flo
     for (int off = 32; off > 0; off >>= 1) k += (uint32_t)__shfl_xor((int)k, off, 64);
     s.k = k;
     s.candidates = C.candidates;
+}
+// the same over a fine grid: the shell's records strided over the lanes, the whole cells one per lane
+__device__ __forceinline__ void wave_gather_fine(const DevPhotonMap &G, f3 p, float r, GatherSums &s) {
+    f3 lo = p - mk3(r, r, r), hi = p + mk3(r, r, r);
+    FineBox F;
+    if (!fine_box(G, lo, hi, F)) {
+        gather_box(G, p, r, s);
+        return;
+    }
+    GatherSums part;
+    part.ldir = mk3(0.0f, 0.0f, 0.0f);
+    part.intensity = mk3(0.0f, 0.0f, 0.0f);
+    part.k = 0;
+    part.candidates = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t shell = 0;
+    visit_fine(
+        G, F,
+        [&](uint32_t first, uint32_t count) {
+            shell += count;
+            first = min(first, G.count);
+            const uint32_t n = min(count, G.count - first);  // guard: stay inside the map
+            for (uint32_t k = lane; k < n; k += 64u) take_record(G, first + k, G.pos_cell[first + k], lo, hi, part);
+        },
+        [&](uint32_t first_cell, uint32_t last_cell, uint32_t count) {
+            const uint32_t c = first_cell + lane;
+            if (c <= last_cell) add_cells(G, c, c, part);
+            if (lane == 0) part.k += count;
+        });
+    s.ldir = mk3(wave_sum_f32(part.ldir.x), wave_sum_f32(part.ldir.y), wave_sum_f32(part.ldir.z));
+    s.intensity = mk3(wave_sum_f32(part.intensity.x), wave_sum_f32(part.intensity.y), wave_sum_f32(part.intensity.z));
+    uint32_t k = part.k;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) k += (uint32_t)__shfl_xor((int)k, off, 64);
+    s.k = k;
+    s.candidates = shell;
 }
 
 }  // namespace rrt

@@ -16,7 +16,7 @@ struct DevCamera {
 };
 
 // photon index in HBM (dev_photon.h)
-#define RRT_DENSE_GRIDS 4
+#define RRT_DENSE_GRIDS 1  // (several grids per map were measured in round 2: no gain for the frames, slower builds; the loops over grids remain)
 struct DenseGrid {
     float lo_x, lo_y, lo_z;   // the grid covers [lo, lo + n * cell)
     uint32_t nx, ny, nz;
@@ -39,8 +39,25 @@ struct DevPhotonMap {
     DenseGrid grid[RRT_DENSE_GRIDS];
     uint32_t n_grids;
     uint32_t n_dense;        // records [0, n_dense) lie in dense cells, [n_dense, count) are outliers
-    float inv_dcell;         // 1 / half_width
+    float inv_dcell;         // div / half_width
     const uint64_t *meta;    // [n] record keys (cell order): ties between equal squared distances (k-nearest estimator, queries)
+    // fine grids (div > 1; dev_photon.h): dense cells of edge half_width / div, and per dense cell the sums of its records
+    const float4 *agg_dir;   // [cells] sum of the normalised incidents, w = records of the cell as uint bits
+    const float4 *agg_rgb;   // [cells] sum of the intensities
+    uint32_t div;
+};
+
+// What the index build decides on the device (photon.hip): the build's kernels read it from HBM, the host reads it back once,
+// when both maps are done.
+struct IndexHeader {
+    DenseGrid grid[RRT_DENSE_GRIDS];
+    uint32_t n_grids, dense_cells;  // k_choose_dense
+    uint32_t n_dense;               // k_dense_starts: records in dense cells (the outliers follow them)
+    uint32_t out_cells, table_size; // k_table_size: occupied outlier cells, slots of their hash table (a power of two)
+    uint32_t error;                 // 1: more dense records than records (internal error)
+    uint32_t trim_steps;            // k_choose_dense: faces moved while trimming the boxes (RRT_INDEX_INFO prints it)
+    uint32_t pad;
+    unsigned long long crowding_sum;  // k_finish_header: sum over the dense cells of count^2
 };
 
 // error bits of TraceArgs::err (1, 2, 4: dev_shade.h)

@@ -184,6 +184,9 @@ struct GatherCounts {
 // local shading terms, the per-light loop, the child rays a Global part asks for.  `occluded(l, so, sd, limit)` answers
 // Scene::shadowtrace for light l (k_trace_shade traces the shadow ray there and then; the pooled-walk experiment,
 // tools/experiments/pool_kernel.patch, had traced it before and looked the answer up).
+// MODE: RRT_MODE_SCENE, RRT_MODE_PHOTON, or MODE_PHOTON_FINE = photon mode over fine photon grids (dev_photon.h), an
+// instance of its own so that the coarse gather keeps its registers
+#define MODE_PHOTON_FINE 2
 template <int MODE, int FEAT, bool FUSE, class Occluded>
 __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o, f3 d, TraceResult tr, Counters &cnt, GatherCounts &gc, NodeOut &N,
                                            Occluded occluded) {
@@ -272,7 +275,7 @@ __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o,
         if (sw > 0.0f) {
             f3 inc, inten;
             gc.queries += 2;
-            const int got = average_photon_at(A.maps, h.position, A.gather_half_width, A.heavy ? A.heavy_threshold : 0xFFFFFFFFu, inc, inten,
+            const int got = average_photon_at<MODE == MODE_PHOTON_FINE>(A.maps, h.position, A.gather_half_width, A.heavy ? A.heavy_threshold : 0xFFFFFFFFu, inc, inten,
                                               gc.gathered, gc.candidates, A.knn_k, KnnColumn{A.knn_ws + i, A.knn_stride});
             if (got == 1) surface = material_render_vueon(S, M, h, inc, inten, -d, cnt);
             N.defer = got == 2;  // `once` is written by k_gather_heavy (or below, if the queue is full)
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
 #endif
 
     // ---- photon mode: file the heavy radiance estimates (one atomic per wave; few waves have any) ----
-    if (MODE == RRT_MODE_PHOTON) {
+    if (MODE != RRT_MODE_SCENE) {
         const HitAttr &h = N.h;
         const unsigned long long md = __ballot(N.defer);
         if (md) {
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
                 } else {  // queue full: this lane gathers for itself after all
                     f3 inc, inten;
                     f3 surface = mk3(0.0f, 0.0f, 0.0f);
-                    if (average_photon_at(A.maps, h.position, A.gather_half_width, 0xFFFFFFFFu, inc, inten, gc.gathered, gc.candidates) == 1)
+                    if (average_photon_at<MODE == MODE_PHOTON_FINE>(A.maps, h.position, A.gather_half_width, 0xFFFFFFFFu, inc, inten, gc.gathered, gc.candidates) == 1)
                         surface = material_render_vueon(S, S.materials[h.material], h, inc, inten, -d, cnt);
                     A.cur.once[i] = make_float4(surface.x, surface.y, surface.z, 0.0f);
                 }
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
 
 // Photon mode: the radiance estimates the trace kernel filed (HeavyRec), one query per wave.  Grid-stride over the
 // records: every wave leaves the loop once the records run out, nothing waits on anything.
+template <bool FINE>
 __global__ __launch_bounds__(64) void k_gather_heavy(TraceArgs A) {
     const DevScene &S = A.S;
     const uint32_t n = min(*A.heavy_count, A.heavy_capacity);
@@ -496,8 +500,13 @@ __global__ __launch_bounds__(64) void k_gather_heavy(TraceArgs A) {
             continue;
         }
         GatherSums reg, cau;
-        wave_gather_box(A.maps[0], h.position, A.gather_half_width, reg);
-        wave_gather_box(A.maps[1], h.position, A.gather_half_width, cau);
+        if (FINE) {
+            wave_gather_fine(A.maps[0], h.position, A.gather_half_width, reg);
+            wave_gather_fine(A.maps[1], h.position, A.gather_half_width, cau);
+        } else {
+            wave_gather_box(A.maps[0], h.position, A.gather_half_width, reg);
+            wave_gather_box(A.maps[1], h.position, A.gather_half_width, cau);
+        }
         gathered += reg.k + cau.k;
         candidates += reg.candidates + cau.candidates;
         f3 inc, inten;
@@ -668,6 +677,13 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
             case FEAT_MESH: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, FEAT_MESH); break;
             default: RRT_EITHER(RRT_WIDE, RRT_MODE_SCENE, FEAT_ALL); break;
         }
+    } else if (a.maps[0].div > 1u) {  // fine photon grids (dev_photon.h): the gather adds whole cells
+        switch (feat) {
+            case 0: RRT_NARROW(MODE_PHOTON_FINE, 0, false); break;
+            case FEAT_CSG: RRT_NARROW(MODE_PHOTON_FINE, FEAT_CSG, false); break;
+            case FEAT_MESH: RRT_NARROW(MODE_PHOTON_FINE, FEAT_MESH, false); break;
+            default: RRT_NARROW(MODE_PHOTON_FINE, FEAT_ALL, false); break;
+        }
     } else {
         switch (feat) {
             case 0: RRT_NARROW(RRT_MODE_PHOTON, 0, false); break;
@@ -682,7 +698,10 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
 }
 void launch_gather_heavy(const TraceArgs &a, hipStream_t stream) {
     if (!a.heavy || a.mode != RRT_MODE_PHOTON) return;
-    hipLaunchKernelGGL(k_gather_heavy, dim3(4096), dim3(64), 0, stream, a);
+    if (a.maps[0].div > 1u)
+        hipLaunchKernelGGL(k_gather_heavy<true>, dim3(4096), dim3(64), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_gather_heavy<false>, dim3(4096), dim3(64), 0, stream, a);
 }
 
 void launch_combine(const TraceArgs &a, hipStream_t stream) {

@@ -322,30 +322,267 @@ __global__ __launch_bounds__(RRT_BLOCK, RRT_SHOOT_WAVES) void k_photon_shoot(Sho
 }
 
 // ---- index build kernels ------------------------------------------------------------------------------
-// sort key of a record: its dense cell index (x fastest), or bit 63 + its hash cell for records outside the dense region
+// Everything the build decides (dense region, record counts, table size) stays on the device in an IndexHeader; kernels that
+// depend on such a number are launched for its upper bound and leave early.
 #define PH_OUTLIER_BIT (1ULL << 63)
-__global__ void k_cell_keys(const float4 *pos, uint32_t n, DevPhotonMap G, uint64_t *keys, uint32_t *idx) {
+
+// canonical sort key of a record: its key with the (light, pass) tag moved down next to the bits in use, so that the radix
+// sort passes over `low_bits + tag bits` instead of 64
+__global__ void k_meta_keys(const uint64_t *meta, uint32_t n, uint32_t low_bits, uint64_t *keys, uint32_t *idx) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float4 p = pos[i];
-    uint32_t cell;
-    if (dense_cell_of(G, p.x, p.y, p.z, cell))
-        keys[i] = cell;
-    else
-        keys[i] = PH_OUTLIER_BIT | cell_key(cell_coord(p.x, G.inv_cell), cell_coord(p.y, G.inv_cell), cell_coord(p.z, G.inv_cell));
+    const uint64_t m = meta[i];
+    keys[i] = low_bits >= 56 ? m : ((m & ((1ULL << low_bits) - 1ULL)) | ((m >> 56) << low_bits));
     idx[i] = i;
 }
-// every `stride`-th position, for the host's choice of the dense region
-__global__ void k_sample_positions(const float4 *pos, uint32_t n, uint32_t stride, uint32_t n_samples, float4 *out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_samples) out[i] = pos[min((uint64_t)i * stride, (uint64_t)n - 1)];
+__global__ void k_meta_or(const uint64_t *meta, uint64_t n, unsigned long long *acc) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = i < n ? meta[i] : 0ULL;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicOr(acc, v);
 }
-// start[c] = first record (of the sorted keys) whose dense cell is >= c, for c = 0 .. cells; n_dense = first outlier
-__global__ void k_dense_starts(const uint64_t *keys, uint32_t n, uint32_t cells, uint32_t *start, uint32_t *n_dense) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > cells) return;
-    const uint64_t want = c == cells ? PH_OUTLIER_BIT : (uint64_t)c;  // every dense key is below `cells`
-    uint32_t lo = 0, hi = n;
+
+// The dense grids.  Photon maps have heavy tails: the reference's infinite planes catch photons (and, behind every
+// landing, shadow photons) thousands of units away, while the queries of a frame fall where the scene is; and they are
+// mostly surfaces, so one box over everything that matters would be nearly all empty cells.  From a strided sample of the
+// positions (canonical order): a grid's box starts as the box of (all but the outermost 0.2 % per side of) the samples no
+// earlier grid holds and is trimmed face by face — always the face whose outer 20 % slab holds the fewest samples — until it
+// fits the cell budget (4 cells per record of the map, between 2^20 and 2^24 cells per grid): sparse tails and empty heights
+// go first, the dense part stays.  Grids are added until fewer than 3 % of the samples are left over (or max_grids).
+// Deterministic in the record set, and only performance depends on it: records outside every box go to the hash grid.
+// One block; every thread carries the same box in registers, the samples live in LDS.
+#define PH_SAMPLES 2048
+#define PH_CHOOSE_THREADS 256
+#define PH_PER_THREAD (PH_SAMPLES / PH_CHOOSE_THREADS)
+// sums of six per-thread counts over the block: shuffles inside the waves, one LDS word per wave and count, ONE barrier (the
+// buffers alternate, so the next reduction cannot overwrite what a slow thread is still reading)
+__device__ __forceinline__ void block_sum6(uint32_t v[6], uint32_t (*part)[PH_CHOOSE_THREADS / 64][6], uint32_t &parity) {
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[f] += (uint32_t)__shfl_xor((int)v[f], off, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int f = 0; f < 6; f++) part[parity][threadIdx.x >> 6][f] = v[f];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < PH_CHOOSE_THREADS / 64; w++) t += part[parity][w][f];
+        v[f] = t;
+    }
+    parity ^= 1u;
+}
+__global__ __launch_bounds__(PH_CHOOSE_THREADS) void k_choose_dense(const float4 *pos, const uint32_t *order, uint32_t n, float cell, float inv_dcell,
+                                                                    uint32_t div, uint32_t max_grids, double budget, IndexHeader *H) {
+    __shared__ float s_v[3][PH_SAMPLES];
+    __shared__ uint32_t s_part[2][PH_CHOOSE_THREADS / 64][6];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_samples = min(n, (uint32_t)PH_SAMPLES), stride = max(1u, n / n_samples);
+    uint32_t parity = 0;
+    // sample tid + j * threads lives in this thread's registers
+    float px[PH_PER_THREAD], py[PH_PER_THREAD], pz[PH_PER_THREAD];
+    uint32_t alive = 0;  // bit j
+    uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < PH_PER_THREAD; j++) {
+        const uint32_t k = tid + (uint32_t)j * PH_CHOOSE_THREADS;
+        float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (k < n_samples) {
+            p = pos[order[min((uint64_t)k * stride, (uint64_t)n - 1)]];
+            if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) alive |= 1u << j;
+        }
+        px[j] = p.x, py[j] = p.y, pz[j] = p.z;
+    }
+    cnt[0] = (uint32_t)__popc(alive);
+    block_sum6(cnt, s_part, parity);
+    if (cnt[0] == 0) {  // no finite position at all: one sample at the origin
+        if (tid == 0) {
+            px[0] = py[0] = pz[0] = 0.0f;
+            alive = 1u;
+        }
+        cnt[0] = 1;
+    }
+    const uint32_t all = cnt[0];
+    uint32_t left = all, n_grids = 0, dense_cells = 0, trim_steps = 0;
+    const float inv = inv_dcell;  // (what the records are filed with)
+    while (n_grids < max_grids && left > 0 && (n_grids == 0 || (uint64_t)left * 100u >= (uint64_t)all * 3u)) {
+        // quantiles of the samples still without a grid: the three axes through one bitonic sort, the other samples at +inf
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PH_PER_THREAD; j++) {
+            const uint32_t k = tid + (uint32_t)j * PH_CHOOSE_THREADS;
+            const bool on = (alive >> j) & 1u;
+            s_v[0][k] = on ? px[j] : INFINITY;
+            s_v[1][k] = on ? py[j] : INFINITY;
+            s_v[2][k] = on ? pz[j] : INFINITY;
+        }
+        for (uint32_t size = 2; size <= PH_SAMPLES; size <<= 1)
+            for (uint32_t step = size >> 1; step > 0; step >>= 1) {
+                __syncthreads();
+                // PH_SAMPLES / 2 pairs over the threads; all loads first, then all stores (no branch in between: the twelve
+                // LDS round trips of a step overlap instead of queueing up behind each other)
+                float x[PH_PER_THREAD / 2][3], y[PH_PER_THREAD / 2][3];
+#pragma unroll
+                for (int q = 0; q < PH_PER_THREAD / 2; q++) {
+                    const uint32_t t = tid + (uint32_t)q * PH_CHOOSE_THREADS;
+                    const uint32_t i = 2u * t - (t & (step - 1u));
+#pragma unroll
+                    for (int a = 0; a < 3; a++) x[q][a] = s_v[a][i], y[q][a] = s_v[a][i + step];
+                }
+#pragma unroll
+                for (int q = 0; q < PH_PER_THREAD / 2; q++) {
+                    const uint32_t t = tid + (uint32_t)q * PH_CHOOSE_THREADS;
+                    const uint32_t i = 2u * t - (t & (step - 1u));
+                    const bool up = (i & size) == 0;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        const float mn = fminf(x[q][a], y[q][a]), mx = fmaxf(x[q][a], y[q][a]);  // (no NaNs here: dead samples are +inf)
+                        s_v[a][i] = up ? mn : mx;
+                        s_v[a][i + step] = up ? mx : mn;
+                    }
+                }
+            }
+        __syncthreads();
+        double lo[3], hi[3];
+        {
+            const uint32_t m = left - 1u;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                lo[a] = (double)s_v[a][(uint32_t)(0.002 * (double)m)];
+                hi[a] = (double)s_v[a][(uint32_t)(0.998 * (double)m)];
+            }
+        }
+        auto cells_of = [&](int a) { return fmax(1.0, ceil((hi[a] - lo[a]) / (double)cell) + 4.0); };
+        double nc[3] = {cells_of(0), cells_of(1), cells_of(2)};  // cells along each axis of the box as it stands
+        for (int it = 0; it < 400 && nc[0] * nc[1] * nc[2] > budget; it++) {
+            double cut[6];  // new position of face 2a (low) / 2a + 1 (high)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                cut[2 * a] = lo[a] + 0.2 * (hi[a] - lo[a]);
+                cut[2 * a + 1] = hi[a] - 0.2 * (hi[a] - lo[a]);
+            }
+            // samples of the box that each new face would leave outside: six counts of at most 8 per thread and 512 per wave,
+            // ten bits each in two words through the wave's shuffles
+            uint32_t pk0 = 0, pk1 = 0;
+#pragma unroll
+            for (int j = 0; j < PH_PER_THREAD; j++) {
+                const double x = (double)px[j], y = (double)py[j], z = (double)pz[j];
+                const bool in = ((alive >> j) & 1u) && x >= lo[0] && x <= hi[0] && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2];
+                pk0 += ((in && x < cut[0]) ? 1u : 0u) + ((in && x > cut[1]) ? 1u << 10 : 0u) + ((in && y < cut[2]) ? 1u << 20 : 0u);
+                pk1 += ((in && y > cut[3]) ? 1u : 0u) + ((in && z < cut[4]) ? 1u << 10 : 0u) + ((in && z > cut[5]) ? 1u << 20 : 0u);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                pk0 += (uint32_t)__shfl_xor((int)pk0, off, 64);
+                pk1 += (uint32_t)__shfl_xor((int)pk1, off, 64);
+            }
+            if ((tid & 63u) == 0) {
+                s_part[parity][tid >> 6][0] = pk0;
+                s_part[parity][tid >> 6][1] = pk1;
+            }
+            __syncthreads();
+            uint32_t loss[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < PH_CHOOSE_THREADS / 64; w++) {
+                const uint32_t a0 = s_part[parity][w][0], a1 = s_part[parity][w][1];
+                loss[0] += a0 & 1023u, loss[1] += (a0 >> 10) & 1023u, loss[2] += a0 >> 20;
+                loss[3] += a1 & 1023u, loss[4] += (a1 >> 10) & 1023u, loss[5] += a1 >> 20;
+            }
+            parity ^= 1u;
+            int best = -1;
+#pragma unroll
+            for (int f = 0; f < 6; f++) {
+                if (nc[f / 2] <= 8.0) continue;  // an axis this thin is not what makes the grid large
+                if (best < 0 || loss[f] < loss[best]) best = f;
+            }
+            if (best < 0) break;
+            if (best & 1)
+                hi[best / 2] = cut[best];
+            else
+                lo[best / 2] = cut[best];
+            nc[best / 2] = cells_of(best / 2);
+            trim_steps++;
+        }
+        double dims[3];
+        for (int a = 0; a < 3; a++) {
+            lo[a] -= 2.0 * (double)cell;
+            dims[a] = cells_of(a);
+        }
+        while (dims[0] * dims[1] * dims[2] > budget) {  // (only if the loop above ran out of iterations)
+            int a = dims[0] >= dims[1] && dims[0] >= dims[2] ? 0 : (dims[1] >= dims[2] ? 1 : 2);
+            dims[a] = fmax(1.0, floor(dims[a] / 2.0));
+        }
+        DenseGrid D;
+        D.lo_x = (float)lo[0], D.lo_y = (float)lo[1], D.lo_z = (float)lo[2];
+        // (the box is chosen in cells of edge r whatever the grid's own cell size, so that it does not depend on `div`)
+        D.nx = (uint32_t)dims[0] * div, D.ny = (uint32_t)dims[1] * div, D.nz = (uint32_t)dims[2] * div;
+        D.cell_base = dense_cells;
+        D.pad = 0;
+        dense_cells += D.nx * D.ny * D.nz;
+        if (tid == 0) H->grid[n_grids] = D;
+        n_grids++;
+        // the samples this grid does not hold, filed like the records will be
+        uint32_t rest[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < PH_PER_THREAD; j++) {
+            if (!((alive >> j) & 1u)) continue;
+            const float fx = dense_coord(px[j], D.lo_x, inv), fy = dense_coord(py[j], D.lo_y, inv), fz = dense_coord(pz[j], D.lo_z, inv);
+            if (fx >= 0.0f && fx < (float)D.nx && fy >= 0.0f && fy < (float)D.ny && fz >= 0.0f && fz < (float)D.nz)
+                alive &= ~(1u << j);
+            else
+                rest[0]++;
+        }
+        block_sum6(rest, s_part, parity);
+        if (rest[0] == left) break;  // a box that holds none of its samples: stop rather than repeat it
+        left = rest[0];
+    }
+    if (tid == 0) {
+        for (uint32_t g = n_grids; g < RRT_DENSE_GRIDS; g++) H->grid[g] = DenseGrid{0.0f, 0.0f, 0.0f, 0u, 0u, 0u, 0u, 0u};
+        H->n_grids = n_grids;
+        H->dense_cells = dense_cells;
+        H->n_dense = 0;
+        H->out_cells = 0;
+        H->table_size = 0;
+        H->error = 0;
+        H->trim_steps = trim_steps;
+        H->pad = 0;
+        H->crowding_sum = 0;
+    }
+}
+
+// the grid a position is filed in (the first whose box holds it) and its cell there; false: an outlier
+__device__ __forceinline__ bool dense_cell_in(const IndexHeader &H, float inv_dcell, float x, float y, float z, uint32_t &cell) {
+    for (uint32_t g = 0; g < H.n_grids; g++) {
+        const DenseGrid &D = H.grid[g];
+        const float fx = dense_coord(x, D.lo_x, inv_dcell), fy = dense_coord(y, D.lo_y, inv_dcell), fz = dense_coord(z, D.lo_z, inv_dcell);
+        if (fx >= 0.0f && fx < (float)D.nx && fy >= 0.0f && fy < (float)D.ny && fz >= 0.0f && fz < (float)D.nz) {
+            cell = D.cell_base + ((uint32_t)fz * D.ny + (uint32_t)fy) * D.nx + (uint32_t)fx;
+            return true;
+        }
+    }
+    return false;
+}
+// sort key of the i-th record in canonical order: its dense cell index (x fastest), or bit 63 + its hash cell for records
+// outside the dense region
+__global__ void k_cell_keys(const float4 *pos, const uint32_t *order, uint32_t n, const IndexHeader *Hp, float inv_cell, float inv_dcell, uint64_t *keys) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pos[order[i]];
+    uint32_t cell;
+    if (dense_cell_in(*Hp, inv_dcell, p.x, p.y, p.z, cell))
+        keys[i] = cell;
+    else
+        keys[i] = PH_OUTLIER_BIT | cell_key(cell_coord(p.x, inv_cell), cell_coord(p.y, inv_cell), cell_coord(p.z, inv_cell));
+}
+// start[c] = first record (of the sorted keys) whose dense cell is >= c, for c = 0 .. cells; n_dense = first outlier.
+// A block's 256 consecutive cells share the part of the keys their answers lie in: two threads find it with a search over all
+// records, the others search inside it (a handful of steps instead of log2 n).
+__device__ __forceinline__ uint32_t first_at_least(const uint64_t *keys, uint32_t lo, uint32_t hi, uint64_t want) {
     while (lo < hi) {
         uint32_t mid = lo + (hi - lo) / 2;
         if (keys[mid] < want)
@@ -353,20 +590,160 @@ __global__ void k_dense_starts(const uint64_t *keys, uint32_t n, uint32_t cells,
         else
             hi = mid;
     }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_dense_starts(const uint64_t *keys, uint32_t n, IndexHeader *H, uint32_t *start) {
+    __shared__ uint32_t s_range[2];
+    const uint32_t cells = H->dense_cells;
+    const uint32_t c0 = blockIdx.x * 256u;
+    if (c0 > cells) return;  // (block-uniform)
+    auto key_of = [&](uint32_t c) { return c >= cells ? PH_OUTLIER_BIT : (uint64_t)c; };  // every dense key is below `cells`
+    if (threadIdx.x < 2) s_range[threadIdx.x] = first_at_least(keys, 0, n, key_of(threadIdx.x == 0 ? c0 : min(c0 + 255u, cells)));
+    __syncthreads();
+    const uint32_t c = c0 + threadIdx.x;
+    if (c > cells) return;
+    const uint32_t lo = first_at_least(keys, s_range[0], s_range[1], key_of(c));
     start[c] = lo;
-    if (c == cells) *n_dense = lo;
+    if (c == cells) {
+        H->n_dense = lo;
+        if (lo > n) H->error |= 1u;
+    }
 }
 // sum of count^2 over the dense cells, into 64 line-separated partial sums
-__global__ void k_dense_crowding(const uint32_t *start, uint32_t cells, unsigned long long *acc) {
+__global__ void k_dense_crowding(const uint32_t *start, const IndexHeader *H, unsigned long long *acc) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v = 0;
-    if (c < cells) {
+    if (c < H->dense_cells) {
         unsigned long long k = start[c + 1] - start[c];
         v = k * k;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(&acc[(blockIdx.x & 63u) * 8u], v);
+}
+// occupied outlier cells = run starts in the outliers' part of the sorted keys.  One atomic per BLOCK into one of 64
+// line-separated counters: an atomic per wave on a single address serialises in the L2 (640 us for 9 M records; this is 4 us)
+#define PH_CELL_COUNTERS 64
+#define PH_CELL_COUNTER_STRIDE 16
+__global__ __launch_bounds__(256) void k_count_cells(const uint64_t *keys, uint32_t n, const IndexHeader *H, uint32_t *count) {
+    __shared__ uint32_t s_part[4];
+    const uint32_t base = min(H->n_dense, n);
+    if ((uint64_t)blockIdx.x * blockDim.x >= n - base) return;  // (block-uniform)
+    uint32_t i = base + blockIdx.x * blockDim.x + threadIdx.x;
+    bool start = i < n && (i == base || keys[i] != keys[i - 1]);
+    unsigned long long m = __ballot(start);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (total) atomicAdd(&count[(blockIdx.x % PH_CELL_COUNTERS) * PH_CELL_COUNTER_STRIDE], total);
+    }
+}
+// the table of the outliers: a power of two of at least twice the occupied cells (the capacity allows for every record being one)
+__global__ void k_table_size(IndexHeader *H, const uint32_t *count, uint32_t capacity) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint32_t cells = 0;
+    for (int k = 0; k < PH_CELL_COUNTERS; k++) cells += count[k * PH_CELL_COUNTER_STRIDE];
+    uint32_t size = 64;
+    while (size < capacity && size < 2u * cells) size <<= 1;
+    H->out_cells = cells;
+    H->table_size = size;
+}
+__global__ void k_fill_table(uint64_t *p, const IndexHeader *H) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H->table_size) p[i] = ~0ULL;
+}
+// the outliers' runs -> table; the table holds absolute record indices
+__global__ void k_insert_cells(const uint64_t *keys, uint32_t n, const IndexHeader *H, uint64_t *table_keys, uint2 *ranges) {
+    const uint32_t base = min(H->n_dense, n);
+    uint32_t i = base + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t key = keys[i];
+    if (i != base && keys[i - 1] == key) return;
+    // run length by binary search for the first index whose key differs
+    uint32_t lo = i + 1, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (keys[mid] == key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    const uint64_t cell = key & ~PH_OUTLIER_BIT;  // what lookup_cell is asked for
+    const uint32_t mask = H->table_size - 1u;
+    uint32_t slot = hash_key(cell) & mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long *)&table_keys[slot], ~0ULL, (unsigned long long)cell);
+        if (prev == ~0ULL) {
+            ranges[slot] = make_uint2(i, lo - i);
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+// Fine grids: per dense cell the sums the gather adds as a whole (dev_photon.h) — normalised incidents and intensities of the
+// cell's records in cell (= canonical) order; a cell of more than 256 records is summed by its whole wave (strided partial sums,
+// fixed butterfly).  agg_dir.w = records of the cell; agg_rgb of an empty cell is not written (nor read).
+__global__ __launch_bounds__(256) void k_cell_sums(const uint32_t *start, const IndexHeader *H, const float4 *dir, const float4 *rgb, float4 *agg_dir,
+                                                   float4 *agg_rgb) {
+    const uint32_t cells = H->dense_cells;
+    if (blockIdx.x * 256u >= cells) return;  // (block-uniform)
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    uint32_t first = 0, count = 0;
+    if (c < cells) {
+        first = start[c];
+        count = start[c + 1] - first;
+    }
+    f3 sd = mk3(0.0f, 0.0f, 0.0f), si = mk3(0.0f, 0.0f, 0.0f);
+    const bool big = count > 256u;
+    if (!big)
+        for (uint32_t k = 0; k < count; k++) {
+            const float4 d = dir[first + k], i = rgb[first + k];
+            sd = sd + mk3(d.x, d.y, d.z);
+            si = si + mk3(i.x, i.y, i.z);
+        }
+    unsigned long long todo = __ballot(big);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ULL;
+        const uint32_t f = (uint32_t)__shfl((int)first, src, 64), n = (uint32_t)__shfl((int)count, src, 64);
+        f3 pd = mk3(0.0f, 0.0f, 0.0f), pi = mk3(0.0f, 0.0f, 0.0f);
+        for (uint32_t k = lane; k < n; k += 64u) {
+            const float4 d = dir[f + k], i = rgb[f + k];
+            pd = pd + mk3(d.x, d.y, d.z);
+            pi = pi + mk3(i.x, i.y, i.z);
+        }
+        pd = mk3(wave_sum_f32(pd.x), wave_sum_f32(pd.y), wave_sum_f32(pd.z));
+        pi = mk3(wave_sum_f32(pi.x), wave_sum_f32(pi.y), wave_sum_f32(pi.z));
+        if ((int)lane == src) {
+            sd = pd;
+            si = pi;
+        }
+    }
+    if (c < cells) {
+        agg_dir[c] = make_float4(sd.x, sd.y, sd.z, __uint_as_float(count));
+        if (count) agg_rgb[c] = make_float4(si.x, si.y, si.z, 0.0f);
+    }
+}
+__global__ void k_finish_header(IndexHeader *H, const unsigned long long *acc) {
+    if (blockIdx.x || threadIdx.x) return;
+    unsigned long long sum = 0;
+    for (int k = 0; k < 64; k++) sum += acc[k * 8];
+    H->crowding_sum = sum;
+}
+// the records in cell order, straight from the buffers as they were filled (`order` = canonical order, then stably by cell);
+// `photon.incident.normalised()` of photon_scene.rs:405 is evaluated once here instead of per query
+__global__ void k_permute_records(const float4 *pos, const float4 *dir, const float4 *rgb, const uint64_t *meta, const uint32_t *order, uint32_t n,
+                                  float4 *pos_out, float4 *dir_out, float4 *rgb_out, uint64_t *meta_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = order[i];
+    const float4 d = dir[j];
+    const f3 v = norm3(mk3(d.x, d.y, d.z));
+    pos_out[i] = pos[j];
+    dir_out[i] = make_float4(v.x, v.y, v.z, 0.0f);
+    rgb_out[i] = rgb[j];
+    meta_out[i] = meta[j];
 }
 __global__ void k_iota(uint32_t *idx, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -384,52 +761,6 @@ __global__ void k_gather_norm(const float4 *src, const uint32_t *idx, uint32_t n
     float4 d = src[idx[i]];
     f3 v = norm3(mk3(d.x, d.y, d.z));
     dst[i] = make_float4(v.x, v.y, v.z, 0.0f);
-}
-// occupied cells = run starts in the sorted keys.  One atomic per BLOCK into one of 64 line-separated counters: an atomic
-// per wave on a single address serialises in the L2 (640 us for 9 M records; this is 4 us)
-#define PH_CELL_COUNTERS 64
-#define PH_CELL_COUNTER_STRIDE 16
-__global__ __launch_bounds__(256) void k_count_cells(const uint64_t *keys, uint32_t n, uint32_t *count) {
-    __shared__ uint32_t s_part[4];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool start = i < n && (i == 0 || keys[i] != keys[i - 1]);
-    unsigned long long m = __ballot(start);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        if (total) atomicAdd(&count[(blockIdx.x % PH_CELL_COUNTERS) * PH_CELL_COUNTER_STRIDE], total);
-    }
-}
-__global__ void k_fill_u64(uint64_t *p, uint32_t n, uint64_t v) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-// keys = the outliers' part of the sorted keys (record `base` onwards); the table holds absolute record indices
-__global__ void k_insert_cells(const uint64_t *keys, uint32_t n, uint32_t base, uint64_t *table_keys, uint2 *ranges, uint32_t mask) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t key = keys[i];
-    if (i != 0 && keys[i - 1] == key) return;
-    // run length by binary search for the first index whose key differs
-    uint32_t lo = i + 1, hi = n;
-    while (lo < hi) {
-        uint32_t mid = lo + (hi - lo) / 2;
-        if (keys[mid] == key)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    const uint64_t cell = key & ~PH_OUTLIER_BIT;  // what lookup_cell is asked for
-    uint32_t slot = hash_key(cell) & mask;
-    for (;;) {
-        unsigned long long prev = atomicCAS((unsigned long long *)&table_keys[slot], ~0ULL, (unsigned long long)cell);
-        if (prev == ~0ULL) {
-            ranges[slot] = make_uint2(base + i, lo - i);
-            return;
-        }
-        slot = (slot + 1) & mask;
-    }
 }
 __global__ void k_strip_key(const uint64_t *meta, uint32_t n, uint64_t *key) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,116 +873,59 @@ static int sort_by_meta(PhotonScratch &W, PhotonBuffers &b) {
     return RRT_OK;
 }
 
-// The dense grids.  Photon maps have heavy tails: the reference's infinite planes catch photons (and, behind every
-// landing, shadow photons) thousands of units away, while the queries of a frame fall where the scene is; and they are
-// mostly surfaces, so one box over everything that matters would be nearly all empty cells.  From a strided sample of the
-// positions: a grid's box starts as the box of (all but the outermost 0.2 % per side of) the samples no earlier grid holds
-// and is trimmed face by face — always the face whose outer 20 % slab holds the fewest samples — until it fits the cell
-// budget (4 cells per record of the map, between 2^20 and 2^24 cells per grid): sparse tails and empty heights go first,
-// the dense part stays.  The first grid ends up around the middle of the scene, the next ones as thin slabs along the
-// floor and walls around it.  Grids are added until fewer than 3 % of the samples are left over (or RRT_DENSE_GRIDS).
-// Deterministic in the record set (the records are in canonical order here), and only performance depends on it:
-// records outside every box go to the hash grid.
-static void choose_dense_box(const std::vector<std::array<float, 3>> &pts, double budget, float cell, DenseGrid &D) {
-    double lo[3], hi[3];
-    {
-        std::vector<float> v(pts.size());
-        for (int a = 0; a < 3; a++) {
-            for (size_t k = 0; k < pts.size(); k++) v[k] = pts[k][a];
-            std::sort(v.begin(), v.end());
-            const size_t m = v.size() - 1;
-            lo[a] = v[(size_t)(0.002 * (double)m)];
-            hi[a] = v[(size_t)(0.998 * (double)m)];
-        }
-    }
-    auto cells_of = [&](int a) { return std::max(1.0, std::ceil((hi[a] - lo[a]) / (double)cell) + 4.0); };
-    std::vector<std::array<float, 3>> inside(pts);  // the box only shrinks: a sample that has left it never counts again
-    for (int it = 0; it < 400 && cells_of(0) * cells_of(1) * cells_of(2) > budget; it++) {
-        double cut[6];  // new position of face 2a (low) / 2a + 1 (high)
-        uint32_t loss[6] = {0, 0, 0, 0, 0, 0};
-        for (int a = 0; a < 3; a++) {
-            cut[2 * a] = lo[a] + 0.2 * (hi[a] - lo[a]);
-            cut[2 * a + 1] = hi[a] - 0.2 * (hi[a] - lo[a]);
-        }
-        size_t kept = 0;
-        for (const auto &p : inside) {
-            if (!(p[0] >= lo[0] && p[0] <= hi[0] && p[1] >= lo[1] && p[1] <= hi[1] && p[2] >= lo[2] && p[2] <= hi[2])) continue;
-            inside[kept++] = p;
-            for (int a = 0; a < 3; a++) {
-                if (p[a] < cut[2 * a]) loss[2 * a]++;
-                if (p[a] > cut[2 * a + 1]) loss[2 * a + 1]++;
-            }
-        }
-        inside.resize(kept);
-        int best = -1;
-        for (int f = 0; f < 6; f++) {
-            if (cells_of(f / 2) <= 8.0) continue;  // an axis this thin is not what makes the grid large
-            if (best < 0 || loss[f] < loss[best]) best = f;
-        }
-        if (best < 0) break;
-        if (best & 1)
-            hi[best / 2] = cut[best];
-        else
-            lo[best / 2] = cut[best];
-    }
-    double dims[3];
-    for (int a = 0; a < 3; a++) {
-        lo[a] -= 2.0 * (double)cell;
-        dims[a] = cells_of(a);
-    }
-    while (dims[0] * dims[1] * dims[2] > budget) {  // (only if the loop above ran out of iterations)
-        int a = dims[0] >= dims[1] && dims[0] >= dims[2] ? 0 : (dims[1] >= dims[2] ? 1 : 2);
-        dims[a] = std::max(1.0, std::floor(dims[a] / 2.0));
-    }
-    D.lo_x = (float)lo[0], D.lo_y = (float)lo[1], D.lo_z = (float)lo[2];
-    D.nx = (uint32_t)dims[0], D.ny = (uint32_t)dims[1], D.nz = (uint32_t)dims[2];
-}
-static int choose_dense_grids(rrt_scene *s, const PhotonBuffers &b, uint32_t n, float cell, PhotonIndex &X) {
-    PhotonScratch &W = s->photon_scratch;
-    const uint32_t n_samples = std::min<uint32_t>(n, 2048), stride = std::max<uint32_t>(1, n / n_samples);
-    int rc = W.t.ensure(n_samples);
+// stable radix sort of (key, index) pairs over the key bits [0, end_bit) on a stream, with the map's own temporary storage
+static int sort_pairs_bits(IndexScratch &W, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in, uint32_t *idx_out, uint32_t n,
+                           uint32_t end_bit, hipStream_t st) {
+    size_t temp_bytes = 0;
+    RRT_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, 0, end_bit, st));
+    int rc = W.sort_temp.ensure(temp_bytes ? temp_bytes : 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_sample_positions, grid_for(n_samples), dim3(256), 0, nullptr, b.pos.p, n, stride, n_samples, W.t.p);
-    std::vector<float4> host(n_samples);
-    RRT_HIP(hipMemcpy(host.data(), W.t.p, (size_t)n_samples * sizeof(float4), hipMemcpyDeviceToHost));
-    std::vector<std::array<float, 3>> pts;
-    pts.reserve(n_samples);
-    for (const float4 &p : host)
-        if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) pts.push_back({p.x, p.y, p.z});
-    if (pts.empty()) pts.push_back({0.0f, 0.0f, 0.0f});
-    const size_t all = pts.size();
-    const double budget = (double)std::min<uint64_t>(std::max<uint64_t>(4ull * n, 1ull << 20), 1ull << 24);
-    X.n_grids = 0;
-    X.dense_cells = 0;
-    const float inv = 1.0f / cell;
-    static const char *max_env = getenv("RRT_DENSE_GRIDS_MAX");  // experiments: fewer grids
-    const uint32_t max_grids = max_env ? std::min<uint32_t>(std::max(1, atoi(max_env)), RRT_DENSE_GRIDS) : 1u;
-    while (X.n_grids < max_grids && !pts.empty() && (X.n_grids == 0 || pts.size() * 100 >= all * 3)) {
-        DenseGrid &D = X.grids[X.n_grids];
-        choose_dense_box(pts, budget, cell, D);
-        D.cell_base = X.dense_cells;
-        D.pad = 0;
-        X.dense_cells += D.nx * D.ny * D.nz;
-        X.n_grids++;
-        std::vector<std::array<float, 3>> rest;  // the samples this grid does not hold, filed like the records will be
-        for (const auto &p : pts) {
-            const float fx = dense_coord(p[0], D.lo_x, inv), fy = dense_coord(p[1], D.lo_y, inv), fz = dense_coord(p[2], D.lo_z, inv);
-            if (!(fx >= 0.0f && fx < (float)D.nx && fy >= 0.0f && fy < (float)D.ny && fz >= 0.0f && fz < (float)D.nz)) rest.push_back(p);
-        }
-        if (rest.size() == pts.size()) break;  // a box that holds none of its samples: stop rather than repeat it
-        pts.swap(rest);
-    }
+    RRT_HIP(rocprim::radix_sort_pairs(W.sort_temp.p, temp_bytes, keys_in, keys_out, idx_in, idx_out, n, 0, end_bit, st));
     return RRT_OK;
 }
+static uint32_t bit_length(uint64_t v) {
+    uint32_t b = 0;
+    while (v) {
+        b++;
+        v >>= 1;
+    }
+    return b;
+}
+// Cells of edge r per dense grid: 4 per record of the map, between 2^20 and 2^24.  A fine grid (cells of edge r / div) covers
+// the same box with div^3 times as many cells, at most 2^27 of them (0.5 GB of start table, 4 GB of per-cell sums).
+static double dense_cell_budget(uint32_t n, uint32_t div) {
+    const uint64_t coarse = std::min<uint64_t>(std::max<uint64_t>(4ull * n, 1ull << 20), 1ull << 24);
+    return (double)std::min<uint64_t>(coarse, (1ull << 27) / ((uint64_t)div * div * div));
+}
+// Dense cell edge = gather half width / div.  Fine cells pay once a query cube holds hundreds of photons (the gather then adds
+// the cells inside the cube as a whole instead of streaming their records): maps of RRT_FINE_GRID_RECORDS records and more.
+// Both maps of a scene get the same div (decided by the regular map).  RRT_DENSE_DIV overrides (1 = the per-record gather
+// everywhere: the parity reference of the fine path).
+#define RRT_FINE_GRID_RECORDS (24u << 20)
+static uint32_t dense_div_for(uint64_t regular_records) {
+    const char *env = getenv("RRT_DENSE_DIV");  // (read at every build: tools switch it between builds)
+    if (env) return (uint32_t)std::min(4, std::max(1, atoi(env)));
+    return regular_records >= RRT_FINE_GRID_RECORDS ? 2u : 1u;
+}
+static uint32_t dense_grids_max() {
+    static const char *max_env = getenv("RRT_DENSE_GRIDS_MAX");  // experiments: more than one grid per map
+    return max_env ? std::min<uint32_t>(std::max(1, atoi(max_env)), RRT_DENSE_GRIDS) : 1u;
+}
 
-static int build_index(rrt_scene *s, int which) {
+// One map's index build, enqueued on the map's own stream; nothing here waits for the device.  The numbers the device
+// decides on the way (the dense region, how many records it holds, the outliers' table size) stay in the IndexHeader; the
+// kernels that need them are launched for their upper bounds.  finish_index reads the header once the stream has drained.
+static int enqueue_index(rrt_scene *s, int which) {
     PhotonBuffers &b = s->local[which];
     PhotonIndex &X = s->index[which];
+    IndexScratch &W = s->index_scratch[which];
     uint32_t n = (uint32_t)b.count;
     const float cell = s->params.gather_half_width;
+    const uint32_t div = dense_div_for(s->local[0].count);
     X.count = n;
+    X.div = div;
     X.inv_cell = 1.0f / (2.0f * cell);
-    X.inv_dcell = 1.0f / cell;
+    X.inv_dcell = (float)div / cell;
     X.table_size = 0;
     X.crowding = 0.0;
     X.n_dense = 0;
@@ -661,81 +935,103 @@ static int build_index(rrt_scene *s, int which) {
     if (n == 0) return RRT_OK;
     if (!(cell > 0.0f) || !std::isfinite(X.inv_dcell)) return fail(RRT_ERR_INVALID, "gather_half_width must be positive");
     int rc;
-    PhotonScratch &W = s->photon_scratch;
+    hipStream_t st = W.stream;
     const bool timing = getenv("RRT_INDEX_INFO") != nullptr;  // debugging aid: host wall clock of the phases (each ends in a sync)
     auto t_phase = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
-        (void)hipDeviceSynchronize();
+        (void)hipStreamSynchronize(st);
         auto t = std::chrono::steady_clock::now();
         fprintf(stderr, "[index %d] %-22s %7.3f ms\n", which, what, std::chrono::duration<double, std::milli>(t - t_phase).count());
         t_phase = t;
     };
-    if ((rc = sort_by_meta(W, b))) return rc;  // canonical order first; the cell sort below is stable
-    lap("sort by key + permute");
-    if ((rc = choose_dense_grids(s, b, n, cell, X))) return rc;
-    lap("choose dense grids");
-    const uint32_t cells = X.dense_cells;
-    DBuf<uint64_t> &keys = W.keys, &keys2 = W.keys2;
-    DBuf<uint32_t> &idx = W.idx, &idx2 = W.idx2, &ncell = W.ncell;
-    if ((rc = keys.ensure(std::max<size_t>(n, 512))) || (rc = keys2.ensure(n)) || (rc = idx.ensure(n)) || (rc = idx2.ensure(n)) ||
-        (rc = ncell.ensure(PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE + 1)))
+    const uint32_t max_grids = dense_grids_max();
+    const double budget = dense_cell_budget(n, div);  // in cells of edge r
+    const size_t max_cells = (size_t)budget * div * div * div * max_grids;
+    size_t table_cap = 64;  // every record an outlier in a cell of its own, at most half full
+    while (table_cap < 2 * (size_t)n) table_cap <<= 1;
+    if ((rc = W.keys.ensure(n)) || (rc = W.keys2.ensure(n)) || (rc = W.idx.ensure(n)) || (rc = W.idx2.ensure(n)) ||
+        (rc = W.ncell.ensure(PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE)) || (rc = W.acc.ensure(512)) || (rc = W.header.ensure(1)) ||
+        (rc = X.pos.ensure(n)) || (rc = X.dir.ensure(n)) || (rc = X.rgb.ensure(n)) || (rc = X.meta.ensure(n)) ||
+        (rc = X.dense_start.ensure(max_cells + 1)) || (rc = X.keys.ensure(table_cap)) || (rc = X.ranges.ensure(table_cap)))
         return rc;
-    hipLaunchKernelGGL(k_cell_keys, grid_for(n), dim3(256), 0, nullptr, b.pos.p, n, X.view(), keys.p, idx.p);
-    if ((rc = sort_pairs(W, keys.p, keys2.p, idx.p, idx2.p, n, nullptr))) return rc;
-    if ((rc = X.pos.ensure(n)) || (rc = X.dir.ensure(n)) || (rc = X.rgb.ensure(n))) return rc;
-    hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.pos.p, idx2.p, n, X.pos.p);
-    hipLaunchKernelGGL(k_gather_norm, grid_for(n), dim3(256), 0, nullptr, b.dir.p, idx2.p, n, X.dir.p);
-    hipLaunchKernelGGL(k_gather<float4>, grid_for(n), dim3(256), 0, nullptr, b.rgb.p, idx2.p, n, X.rgb.p);
-    if ((rc = X.meta.ensure(n))) return rc;
-    hipLaunchKernelGGL(k_gather<uint64_t>, grid_for(n), dim3(256), 0, nullptr, b.meta.p, idx2.p, n, X.meta.p);
+    if (div > 1 && ((rc = X.agg_dir.ensure(max_cells)) || (rc = X.agg_rgb.ensure(max_cells)))) return rc;
+    IndexHeader *H = W.header.p;
+    // canonical order: the records by key (light, pass, photon index, landing, sub-index), over the key bits in use only
+    const uint32_t low_bits = std::min<uint32_t>(56u, bit_length(s->meta_or & 0x00FFFFFFFFFFFFFFull)), tag_bits = bit_length(s->meta_or >> 56);
+    hipLaunchKernelGGL(k_meta_keys, grid_for(n), dim3(256), 0, st, b.meta.p, n, low_bits, W.keys.p, W.idx.p);
+    if ((rc = sort_pairs_bits(W, W.keys.p, W.keys2.p, W.idx.p, W.idx2.p, n, std::max(1u, low_bits + tag_bits), st))) return rc;
+    lap("sort by key");
+    hipLaunchKernelGGL(k_choose_dense, dim3(1), dim3(PH_CHOOSE_THREADS), 0, st, b.pos.p, W.idx2.p, n, cell, X.inv_dcell, div, max_grids, budget, H);
+    lap("choose dense grids");
+    // then stably by cell
+    hipLaunchKernelGGL(k_cell_keys, grid_for(n), dim3(256), 0, st, b.pos.p, W.idx2.p, n, H, X.inv_cell, X.inv_dcell, W.keys.p);
+    if ((rc = sort_pairs_bits(W, W.keys.p, W.keys2.p, W.idx2.p, W.idx.p, n, 64, st))) return rc;
+    hipLaunchKernelGGL(k_permute_records, grid_for(n), dim3(256), 0, st, b.pos.p, b.dir.p, b.rgb.p, b.meta.p, W.idx.p, n, X.pos.p, X.dir.p, X.rgb.p,
+                       X.meta.p);
     lap("cell sort + permute");
-    // dense part: the start table, and where the outliers begin
-    if ((rc = X.dense_start.ensure((size_t)cells + 1))) return rc;
-    uint32_t *n_dense_dev = ncell.p + PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE;
-    hipLaunchKernelGGL(k_dense_starts, grid_for((uint64_t)cells + 1), dim3(256), 0, nullptr, keys2.p, n, cells, X.dense_start.p, n_dense_dev);
-    // outliers: occupied hash cells -> table
-    RRT_HIP(hipMemsetAsync(ncell.p, 0, PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE * sizeof(uint32_t), nullptr));
-    uint32_t n_dense = 0;
-    RRT_HIP(hipMemcpy(&n_dense, n_dense_dev, sizeof(n_dense), hipMemcpyDeviceToHost));
-    if (n_dense > n) return fail(RRT_ERR_DEVICE, "photon index: bad dense record count");
-    X.n_dense = n_dense;
-    const uint32_t n_out = n - n_dense;
-    uint32_t out_cells = 0;
-    if (n_out) {
-        hipLaunchKernelGGL(k_count_cells, grid_for(n_out), dim3(256), 0, nullptr, keys2.p + n_dense, n_out, ncell.p);
-        uint32_t part[PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE];
-        RRT_HIP(hipMemcpy(part, ncell.p, sizeof(part), hipMemcpyDeviceToHost));
-        for (int k = 0; k < PH_CELL_COUNTERS; k++) out_cells += part[k * PH_CELL_COUNTER_STRIDE];
-    }
-    if (out_cells >= (1u << 30)) return fail(RRT_ERR_LIMIT, "photon index above 2^30 occupied outlier cells");
-    uint32_t size = 64;
-    while (size < 2 * out_cells) size <<= 1;
-    if ((rc = X.keys.ensure(size)) || (rc = X.ranges.ensure(size))) return rc;
-    X.table_size = size;
-    hipLaunchKernelGGL(k_fill_u64, grid_for(size), dim3(256), 0, nullptr, X.keys.p, size, ~0ULL);
-    if (n_out) hipLaunchKernelGGL(k_insert_cells, grid_for(n_out), dim3(256), 0, nullptr, keys2.p + n_dense, n_out, n_dense, X.keys.p, X.ranges.p, size - 1);
+    // dense part: the start table, and where the outliers begin; outliers: occupied hash cells -> table
+    hipLaunchKernelGGL(k_dense_starts, grid_for((uint64_t)max_cells + 1), dim3(256), 0, st, W.keys2.p, n, H, X.dense_start.p);
+    RRT_HIP(hipMemsetAsync(W.ncell.p, 0, PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE * sizeof(uint32_t), st));
+    RRT_HIP(hipMemsetAsync(W.acc.p, 0, 512 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_count_cells, grid_for(n), dim3(256), 0, st, W.keys2.p, n, H, W.ncell.p);
+    hipLaunchKernelGGL(k_table_size, dim3(1), dim3(64), 0, st, H, W.ncell.p, (uint32_t)std::min<size_t>(table_cap, 1u << 31));
+    hipLaunchKernelGGL(k_fill_table, grid_for(table_cap), dim3(256), 0, st, X.keys.p, H);
+    hipLaunchKernelGGL(k_insert_cells, grid_for(n), dim3(256), 0, st, W.keys2.p, n, H, X.keys.p, X.ranges.p);
+    // how crowded the cells are where the photons are (sizes the default heavy-query threshold, rrt_photon_build)
+    hipLaunchKernelGGL(k_dense_crowding, grid_for(max_cells), dim3(256), 0, st, X.dense_start.p, H, W.acc.p);
+    hipLaunchKernelGGL(k_finish_header, dim3(1), dim3(64), 0, st, H, W.acc.p);
+    if (div > 1)
+        hipLaunchKernelGGL(k_cell_sums, grid_for(max_cells), dim3(256), 0, st, X.dense_start.p, H, X.dir.p, X.rgb.p, X.agg_dir.p, X.agg_rgb.p);
     RRT_HIP(hipGetLastError());
-    {   // how crowded the cells are where the photons are (sizes the default heavy-query threshold, rrt_photon_build)
-        DBuf<uint64_t> &acc = W.keys;  // the unsorted cell keys are no longer needed
-        RRT_HIP(hipMemsetAsync(acc.p, 0, 512 * sizeof(unsigned long long), nullptr));
-        hipLaunchKernelGGL(k_dense_crowding, grid_for(cells), dim3(256), 0, nullptr, X.dense_start.p, cells, (unsigned long long *)acc.p);
-        unsigned long long part[512];
-        RRT_HIP(hipMemcpy(part, acc.p, sizeof(part), hipMemcpyDeviceToHost));
-        unsigned long long sum = 0;
-        for (int k = 0; k < 64; k++) sum += part[k * 8];
-        X.crowding = (double)sum / (double)n;
-    }
     lap("tables + crowding");
+    RRT_HIP(hipMemcpyAsync(W.host_header, H, sizeof(IndexHeader), hipMemcpyDeviceToHost, st));
+    return RRT_OK;
+}
+// after the map's stream has drained: what the device decided becomes the view the render kernels get
+static int finish_index(rrt_scene *s, int which) {
+    PhotonIndex &X = s->index[which];
+    if (X.count == 0) return RRT_OK;
+    const IndexHeader &H = *s->index_scratch[which].host_header;
+    const uint32_t n = (uint32_t)X.count;
+    if (H.error || H.n_dense > n || H.n_grids > RRT_DENSE_GRIDS || (H.table_size & (H.table_size - 1u)) || H.table_size < 64u || H.table_size > X.keys.cap)
+        return fail(RRT_ERR_DEVICE, "photon index: inconsistent header (internal error)");
+    for (uint32_t g = 0; g < RRT_DENSE_GRIDS; g++) X.grids[g] = H.grid[g];
+    X.n_grids = H.n_grids;
+    X.dense_cells = H.dense_cells;
+    X.n_dense = H.n_dense;
+    X.table_size = H.table_size;
+    X.crowding = (double)H.crowding_sum / (double)n;
     if (getenv("RRT_INDEX_INFO")) {
-        fprintf(stderr, "[index %d] %u records: %u in %u dense grids (cell %.3g, %u cells), %u outliers in %u hash cells; crowding %.1f\n", which, n,
-                n_dense, X.n_grids, cell, cells, n_out, out_cells, X.crowding);
+        fprintf(stderr, "[index %d] %u records: %u in %u dense grids (cell %.3g, %u cells), %u outliers in %u hash cells (table %u); crowding %.1f; %u trimming steps\n",
+                which, n, X.n_dense, X.n_grids, s->params.gather_half_width, X.dense_cells, n - X.n_dense, H.out_cells, H.table_size, X.crowding, H.trim_steps);
         for (uint32_t g = 0; g < X.n_grids; g++)
-            fprintf(stderr, "[index %d]   grid %u: %u x %u x %u from %.3f %.3f %.3f\n", which, g, X.grids[g].nx, X.grids[g].ny, X.grids[g].nz,
-                    X.grids[g].lo_x, X.grids[g].lo_y, X.grids[g].lo_z);
+            fprintf(stderr, "[index %d]   grid %u: %u x %u x %u from %.9g %.9g %.9g\n", which, g, X.grids[g].nx, X.grids[g].ny, X.grids[g].nz, X.grids[g].lo_x,
+                    X.grids[g].lo_y, X.grids[g].lo_z);
     }
-    RRT_HIP(hipDeviceSynchronize());
     s->map_view[which] = X.view();
+    return RRT_OK;
+}
+static int ensure_index_streams(rrt_scene *s) {
+    for (int w = 0; w < 2; w++) {
+        IndexScratch &W = s->index_scratch[w];
+        if (!W.stream) RRT_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+        if (!W.done) RRT_HIP(hipEventCreateWithFlags(&W.done, hipEventDisableTiming));
+        if (!W.host_header) RRT_HIP(hipHostMalloc((void **)&W.host_header, sizeof(IndexHeader), hipHostMallocDefault));
+    }
+    return RRT_OK;
+}
+// the key bits of records that did not come from rrt_photon_shoot (imports, appended segments, files)
+static int note_foreign_keys(rrt_scene *s, const uint64_t *meta_dev, uint64_t count) {
+    if (count == 0) return RRT_OK;
+    int rc;
+    if (!s->meta_or_dev.p) {
+        if ((rc = s->meta_or_dev.ensure(1))) return rc;
+        RRT_HIP(hipMemsetAsync(s->meta_or_dev.p, 0, sizeof(unsigned long long), nullptr));
+    }
+    hipLaunchKernelGGL(k_meta_or, grid_for(count), dim3(256), 0, nullptr, meta_dev, count, s->meta_or_dev.p);
+    RRT_HIP(hipGetLastError());
+    s->meta_or_pending = true;
     return RRT_OK;
 }
 
@@ -773,6 +1069,9 @@ int rrt_photon_begin(rrt_scene *s, uint64_t seed) {
     s->seed = seed;
     s->maps_built = false;
     s->local[0].count = s->local[1].count = 0;
+    s->meta_or = 0;
+    s->meta_or_pending = false;
+    if (s->meta_or_dev.p) RRT_HIP(hipMemset(s->meta_or_dev.p, 0, sizeof(unsigned long long)));
     s->seeds.clear();
     for (size_t i = 0; i < s->lights.size(); i++) s->seeds.push_back(std::make_unique<CausticSeeds>());
     s->stats.photons_emitted = 0;
@@ -790,6 +1089,8 @@ int rrt_photon_shoot(rrt_scene *s, int light, int pass, uint64_t first, uint64_t
     if (count == 0) return RRT_OK;
     if (count >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 photons in one call");
     if (first + count >= (1ull << 40)) return fail(RRT_ERR_LIMIT, "photon index above 2^40");
+    // key bits this call can set (index * 65536 + landing * 1024 + sub-index, tag above bit 56): the index build sorts over those
+    s->meta_or |= ((uint64_t)(light * 2 + pass) << 56) | ((1ULL << bit_length((first + count - 1) * 65536ULL + 65535ULL)) - 1ULL);
     CausticSeeds &cs = *s->seeds[light];
     if (pass == 1 && cs.count == 0) {
         // point_light.rs:106-108 returns an empty Vec; directional_point_light.rs:110 would panic on unwrap
@@ -931,15 +1232,31 @@ int rrt_photon_build(rrt_scene *s) {
     if (int rc_dev = use_scene_device(s)) return rc_dev;
     if (!s->flattened) return fail(RRT_ERR_STATE, "rrt_photon_begin has not been called");
     drop_render_workers(s);  // the index arrays they read are rebuilt
-    hipEvent_t e0 = s->events[0], e1 = s->events[1];
-    RRT_HIP(hipEventRecord(e0, nullptr));
     int rc;
+    if ((rc = ensure_index_streams(s))) return rc;
+    if (s->meta_or_pending) {  // records that were imported, appended or loaded: which key bits they use
+        unsigned long long v = 0;
+        RRT_HIP(hipMemcpy(&v, s->meta_or_dev.p, sizeof(v), hipMemcpyDeviceToHost));
+        s->meta_or |= v;
+        s->meta_or_pending = false;
+    }
+    // The two maps side by side on a stream each (photon_scene.rs:70-82 builds its two trees in two threads), both behind
+    // whatever filled the buffers on the null stream; the host waits once, for both, and reads the two headers.
+    hipEvent_t e0 = s->events[0], e1 = s->events[1];
+    IndexScratch &W0 = s->index_scratch[0], &W1 = s->index_scratch[1];
+    RRT_HIP(hipEventRecord(e0, nullptr));
+    RRT_HIP(hipStreamWaitEvent(W0.stream, e0, 0));
+    RRT_HIP(hipStreamWaitEvent(W1.stream, e0, 0));
     for (int w = 0; w < 2; w++)
-        if ((rc = build_index(s, w))) return rc;
-    RRT_HIP(hipEventRecord(e1, nullptr));
+        if ((rc = enqueue_index(s, w))) return rc;
+    RRT_HIP(hipEventRecord(W1.done, W1.stream));
+    RRT_HIP(hipStreamWaitEvent(W0.stream, W1.done, 0));
+    RRT_HIP(hipEventRecord(e1, W0.stream));
     RRT_HIP(hipEventSynchronize(e1));
     float ms = 0.0f;
     RRT_HIP(hipEventElapsedTime(&ms, e0, e1));
+    for (int w = 0; w < 2; w++)
+        if ((rc = finish_index(s, w))) return rc;
     s->stats.ms_photon_build = ms;
     s->stats.photons_stored_regular = s->local[0].count;
     s->stats.photons_stored_caustic = s->local[1].count;
@@ -1042,6 +1359,7 @@ int rrt_photon_import_device(rrt_scene *s, int which, const float *pos4_dev, con
         RRT_HIP(hipMemcpy(b.dir.p, incident4_dev, count * 16, hipMemcpyDeviceToDevice));
         RRT_HIP(hipMemcpy(b.rgb.p, intensity4_dev, count * 16, hipMemcpyDeviceToDevice));
         RRT_HIP(hipMemcpy(b.meta.p, meta_dev, count * 8, hipMemcpyDeviceToDevice));
+        if ((rc = note_foreign_keys(s, b.meta.p, count))) return rc;
     }
     b.count = count;
     s->maps_built = false;
@@ -1073,6 +1391,7 @@ int rrt_photon_append_device(rrt_scene *s, int which, const float *pos4_dev, con
     RRT_HIP(hipMemcpy(b.dir.p + b.count, incident4_dev, count * 16, hipMemcpyDeviceToDevice));
     RRT_HIP(hipMemcpy(b.rgb.p + b.count, intensity4_dev, count * 16, hipMemcpyDeviceToDevice));
     RRT_HIP(hipMemcpy(b.meta.p + b.count, meta_dev, count * 8, hipMemcpyDeviceToDevice));
+    if ((rc = note_foreign_keys(s, b.meta.p + b.count, count))) return rc;
     b.count += count;
     s->maps_built = false;
     return RRT_OK;
@@ -1270,6 +1589,10 @@ int rrt_photon_load(rrt_scene *s, const char *path) {
                 }
             }
         b.count = h.count[w];
+        if (int rc = note_foreign_keys(s, b.meta.p, b.count)) {
+            fclose(f);
+            return rc;
+        }
     }
     fclose(f);
     s->seed = h.seed;

@@ -73,6 +73,9 @@ DevPhotonMap PhotonIndex::view() const {
     m.n_dense = n_dense;
     m.inv_dcell = inv_dcell;
     m.meta = meta.p;
+    m.agg_dir = agg_dir.p;
+    m.agg_rgb = agg_rgb.p;
+    m.div = div;
     return m;
 }
 

@@ -91,6 +91,8 @@ struct PhotonIndex {
     DBuf<uint64_t> keys;     // outliers' hash table
     DBuf<uint2> ranges;
     DBuf<uint32_t> dense_start;  // dense grid: first record of every cell (+ one past the last)
+    DBuf<float4> agg_dir, agg_rgb;  // fine grids (div > 1): per dense cell the sums of its records
+    uint32_t div = 1;            // dense cell edge = gather half width / div
     uint32_t table_size = 0;
     uint64_t count = 0;
     float inv_cell = 0.0f;   // hash grid, cell edge 2r
@@ -110,6 +112,23 @@ struct PhotonScratch {
     DBuf<uint8_t> sort_temp;
     PhotonBuffers stage[2];    // segmented staging of one rrt_photon_shoot call (photon.hip)
     DBuf<uint32_t> seg_counts;
+};
+// Work arrays of one map's index build.  The two maps are built side by side on streams of their own (the reference builds its
+// two kd-trees in two threads, photon_scene.rs:70-82), so each has its own set.
+struct IndexScratch {
+    DBuf<uint32_t> idx, idx2, ncell;
+    DBuf<uint64_t> keys, keys2;
+    DBuf<unsigned long long> acc;
+    DBuf<uint8_t> sort_temp;
+    DBuf<IndexHeader> header;
+    IndexHeader *host_header = nullptr;  // pinned
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    ~IndexScratch() {
+        if (host_header) (void)hipHostFree(host_header);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (done) (void)hipEventDestroy(done);
+    }
 };
 struct CausticSeeds {
     DBuf<float4> pos, dir;
@@ -178,6 +197,12 @@ struct rrt_scene {
     std::vector<std::unique_ptr<rrt::CausticSeeds>> seeds;  // per light
     rrt::PhotonIndex index[2];
     rrt::PhotonScratch photon_scratch;
+    rrt::IndexScratch index_scratch[2];
+    // bits of the record keys in use (rrt_photon_shoot knows its index range; imported / loaded records are looked at on the
+    // device): the canonical sort of the index build only passes over those
+    uint64_t meta_or = 0;
+    rrt::DBuf<unsigned long long> meta_or_dev;  // OR of the keys of imported records (read at the next build)
+    bool meta_or_pending = false;
 
     ~rrt_scene();
 };

@@ -86,6 +86,51 @@ def test_heavy_radiance_estimates_gathered_by_whole_waves(repo):
     assert not np.array_equal(bits(low.render(cam)[0]), bits(f_off[0]))        # the other order really was used
 
 
+@pytest.mark.parametrize("name,photons,caustic,div", [("pm_caustics", 60000, 4000, 2), ("scene2", 120000, 5000, 2), ("pm_caustics", 60000, 4000, 4),
+                                                      ("pm_caustics", 60000, 4000, 3)])
+def test_fine_photon_grids_gather_the_same_photons(repo, monkeypatch, name, photons, caustic, div):
+    """Fine photon grids (dense cells of edge r / div; what maps of tens of millions of records get): the cells strictly inside a
+    query cube are added from per-cell sums instead of being streamed record by record (dev_photon.h).  Forced here on small
+    maps through RRT_DENSE_DIV: the same photons per query as the per-record gather (div = 1) and as the oracle's kd-tree
+    (counts exact), ids / depth bit-exact, colours within the rounding of another summation order; with the heavy-query
+    kernel (a wave per query) on and off; deterministic and independent of the banding; queries through the index unchanged."""
+    OFF = 0xFFFFFFFF
+    monkeypatch.setenv("RRT_DENSE_DIV", "1")
+    cpu, coarse, cam = pair(repo, name, photons, caustic, gather_heavy_threshold=OFF)
+    cpu.pre_render(11)
+    coarse.pre_render(11)
+    cam.width, cam.height = 176, 128
+    f_coarse = coarse.render(cam)
+    st_coarse = coarse.stats()
+    rgb_c, depth_c, id_c = cpu.render(cam)
+    assert st_coarse["photons_gathered"] == cpu.stats()["photons_gathered"] > 50000
+    pts = coarse.photon_read(0)["position"][:: max(1, photons // 40)][:32].copy()
+    q_coarse = coarse.photon_query(0, pts, 0.1, 16)
+    monkeypatch.setenv("RRT_DENSE_DIV", str(div))
+    for threshold in (OFF, 24):
+        _, fine, _ = pair(repo, name, photons, caustic, gather_heavy_threshold=threshold)
+        fine.pre_render(11)
+        f = fine.render(cam)
+        st = fine.stats()
+        assert np.array_equal(f[2], f_coarse[2]) and np.array_equal(bits(f[1]), bits(f_coarse[1]))
+        for k in ("photons_gathered", "gather_queries", "rays_secondary"):
+            assert st[k] == st_coarse[k], (k, threshold)
+        assert st["gather_candidates"] < st_coarse["gather_candidates"]         # whole cells were not read
+        d = np.abs(rrt.quantise(f[0]).astype(int) - rrt.quantise(f_coarse[0]).astype(int))
+        assert d.max() <= 1 and d.mean() < 0.02, (d.max(), d.mean())
+        dq = np.abs(ob.quantise(rgb_c).astype(int) - rrt.quantise(f[0]).astype(int))
+        assert dq.mean() < 0.05 and (dq > 1).mean() < 1e-3, (dq.mean(), dq.max())
+        assert np.array_equal(bits(f[0]), bits(fine.render(cam)[0]))             # deterministic
+        top, bottom = fine.render(cam, 0, 56), fine.render(cam, 56, cam.height)
+        assert np.array_equal(bits(f[0]), bits(np.concatenate([top[0], bottom[0]])))
+        q = fine.photon_query(0, pts, 0.1, 16)                                    # the index itself: same answers
+        assert np.array_equal(q[0], q_coarse[0])
+        for i, c in enumerate(q[0]):                                              # (rows are filled up to min(count, k_max))
+            m = min(int(c), 16)
+            assert np.array_equal(q[1][i, :m], q_coarse[1][i, :m]) and np.array_equal(bits(q[2][i, :m]), bits(q_coarse[2][i, :m]))
+    assert not np.array_equal(bits(f[0]), bits(f_coarse[0]))                     # the other order really was used
+
+
 @pytest.mark.parametrize("name,photons,caustic,k", [("pm_caustics", 60000, 4000, 4), ("scene2", 120000, 5000, 8), ("pm_caustics", 60000, 4000, 1)])
 def test_k_nearest_estimator_matches_get_n_within_radius(repo, name, photons, caustic, k):
     """rrt_params.gather_k: PhotonTree::get_n_within_radius (photon_tree.rs:41-50) as the radiance estimator of the vueon
