@@ -8,8 +8,9 @@ Mrays/s = (primary + secondary + shadow rays traced) / wall time, frames rendere
 
 N ranks render ONE frame together (north_star: "image tiles shard over GPUs"): its rows are dealt round-robin in groups
 of 8 (rrt_render_interleaved_device: contiguous bands would leave the ranks with the sky idle), every rank renders its
-share into one packed buffer, and ONE RCCL gather per frame brings the shares to rank 0, which puts the rows back in
-image order.  Total work is fixed as N grows: "scaling": "strong".  The gather of frame f overlaps the rendering of
+share, quantises it on the device to what the reference finally writes (framebuffer.rs:96-130: u8 rgb + u8 depth, 4 bytes per
+pixel: 33 MB per 4K frame instead of 166 MB of f32 rgb + depth + id) and ONE RCCL gather per frame brings the shares to rank 0,
+which puts the rows back in image order with one kernel (rrt_assemble_frame_device).  Total work is fixed as N grows: "scaling": "strong".  The gather of frame f overlaps the rendering of
 frame f + 1 (two buffers); `collective_ms` is that gather timed on its own (after the timed region, five repeats),
 `collective_gb_per_s` the bytes rank 0 receives over that time, `collective_exposed_ms` what of it the timed region had to
 wait for per step.  At N = 1 there is no collective and the frame is
@@ -127,7 +128,7 @@ def photon_pass_leg(rrt, torch, D, dist, rank, world, device, stage_host, photon
     info = None
     for seed in (1, 2):  # the first pass sizes buffers and warms RCCL up; the second is reported
         info = D.photon_pass(scene, ex, 1, photons, caustic, seed, rank, world, dist, "cpu" if stage_host else device)
-    fg = D.FrameGather(rrt, cam, rank, world, dist, device, interleave=interleave, stage_host=stage_host)
+    fg = D.FrameGather(rrt, cam, rank, world, dist, device, interleave=interleave, stage_host=stage_host, wire="u8" if world > 1 else "f32")
     stream = torch.cuda.current_stream().cuda_stream
     times = {}
     for it in range(2):
@@ -192,7 +193,8 @@ def main():
     t0 = time.perf_counter()
     scene.pre_render(seed=1)
     t_pre = time.perf_counter() - t0
-    fg = D.FrameGather(rrt, cam, rank, world, dist, device, interleave=args.interleave, stage_host=rehearsal)
+    # N > 1: a rank sends its share as the reference finally writes it (u8 rgb + u8 depth, 4 bytes per pixel); N = 1 renders f32
+    fg = D.FrameGather(rrt, cam, rank, world, dist, device, interleave=args.interleave, stage_host=rehearsal, wire="u8" if world > 1 else "f32")
     stream = torch.cuda.current_stream().cuda_stream
 
     def sync():
@@ -296,11 +298,12 @@ def main():
             "collective_ms": gather_alone_ms if world > 1 else 0.0,
             "collective_gb_per_s": (gather_bytes / (gather_alone_ms * 1e-3) / 1e9) if world > 1 and gather_alone_ms > 0 else None,
             "collective_exposed_ms": wait_ms / args.steps if world > 1 else 0.0,
+            "collective_bytes": gather_bytes if world > 1 else 0,
             "config": {
                 "workload": "BASELINE configs[3]: %d-triangle mesh (13x13 grid of assets/models/teapot.obj) + floor, 1 point light, 3840x2160, "
                             "%s; one frame per step, frames one at a time" % (ntri, args.variant),
                 "rays_per_frame": int(total_rays // max(1, args.steps)),
-                "parallelism": ("one GPU" if world == 1 else "rows of each frame dealt to %d ranks in groups of %d, one gather per frame to rank 0 (%d bytes), "
+                "parallelism": ("one GPU" if world == 1 else "rows of each frame dealt to %d ranks in groups of %d, one gather per frame to rank 0 (%d bytes of u8 rgb + depth), "
                                 "overlapped with the next frame" % (world, args.interleave, gather_bytes)) + (" (REHEARSAL: ranks share devices, gloo + host staging)" if rehearsal else ""),
                 "frames_repeated": repeated,
                 "bvh_box_tests_per_ray": st["bvh_nodes_visited"] / max(1, st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]),

@@ -306,6 +306,18 @@ int rrt_render_interleaved_device(rrt_scene *s, const rrt_camera *cam, uint32_t 
                                   uint32_t group_stride, float *rgb_dev, float *depth_dev, uint32_t *object_id_dev,
                                   void *hip_stream);
 
+/* Multi-GPU frames (the thread split of camera.rs:14-43 with ranks for threads): what a rank hands to rank 0 is
+ * its share as the reference finally writes it, FrameBuffer::write_rgb_file / write_depth_file's `(c * 255.0) as u8`
+ * (framebuffer.rs:96-130), 4 bytes r g b d per pixel instead of 20 bytes of f32 rgb + depth + id.  rrt_quantise_pack_device
+ * packs a rendered share ([n_pixels] rgb f32 x 3 + depth f32, in HBM) into rgbd_dev [n_pixels][4]; rrt_assemble_frame_device
+ * is FrameBuffer::combine_rows (framebuffer.rs:52-69) on rank 0: the gathered shares parts_dev [world][rows_max][width][4]
+ * -> the P6 payload rgb_dev [height][width][3] and the P5 payload depth_dev [height][width] in image order.  row_group as in
+ * rrt_render_interleaved_device (rank r rendered the groups r, r + world, ...); row_group = 0: contiguous bands, height /
+ * world rows each and the remainder on the last rank (camera.rs:16-31).  Both run on `hip_stream` and return at once.     */
+int rrt_quantise_pack_device(const float *rgb_dev, const float *depth_dev, size_t n_pixels, uint8_t *rgbd_dev, void *hip_stream);
+int rrt_assemble_frame_device(const uint8_t *parts_dev, uint32_t world, uint32_t rows_max, uint32_t width, uint32_t height,
+                              uint32_t row_group, uint8_t *rgb_dev, uint8_t *depth_dev, void *hip_stream);
+
 /* replaces: Environment::raytrace (environment.rs:27), batched: n rays, origins/directions
  * [n][3] on the host.                                                                      */
 int rrt_raytrace(rrt_scene *s, const float *origins, const float *directions, size_t n, float *rgb,

@@ -217,6 +217,9 @@ extern "C" {
     pub fn rrt_interleaved_row_count(height: u32, group_rows: u32, first_group: u32, group_stride: u32) -> u32;
     pub fn rrt_render_interleaved_device(s: *mut rrt_scene, cam: *const rrt_camera, group_rows: u32, first_group: u32, group_stride: u32,
                                          rgb_dev: *mut f32, depth_dev: *mut f32, object_id_dev: *mut u32, hip_stream: *mut c_void) -> c_int;
+    pub fn rrt_quantise_pack_device(rgb_dev: *const f32, depth_dev: *const f32, n_pixels: usize, rgbd_dev: *mut u8, hip_stream: *mut c_void) -> c_int;
+    pub fn rrt_assemble_frame_device(parts_dev: *const u8, world: u32, rows_max: u32, width: u32, height: u32, row_group: u32,
+                                     rgb_dev: *mut u8, depth_dev: *mut u8, hip_stream: *mut c_void) -> c_int;
     pub fn rrt_raytrace(s: *mut rrt_scene, origins: *const f32, directions: *const f32, n: usize, rgb: *mut f32, depth: *mut f32,
                         object_id: *mut u32) -> c_int;
     pub fn rrt_trace(s: *mut rrt_scene, origins: *const f32, directions: *const f32, n: usize, object_id: *mut u32, prim_id: *mut u32,

@@ -93,6 +93,8 @@ _sig("rrt_trace", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _u32p, _u32p, _
 _sig("rrt_shadowtrace", C.c_int, C.c_void_p, _f32p, _f32p, _f32p, C.c_size_t, _u8p)
 _sig("rrt_interleaved_row_count", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 _sig("rrt_render_interleaved_device", C.c_int, C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("rrt_quantise_pack_device", C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+_sig("rrt_assemble_frame_device", C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("rrt_photon_reserve", C.c_int, C.c_void_p, C.c_int, C.c_uint64)
 _sig("rrt_photon_append_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 _sig("rrt_trace_noalloc", C.c_int, C.c_void_p, _f32p, _f32p, C.c_size_t, _u32p, _u32p, _f32p, _f32p, _f32p, _f32p)
@@ -122,6 +124,16 @@ def interleaved_rows(height, group_rows, first_group, group_stride):
     rows = [y for y in range(height) if (y // group_rows) % group_stride == first_group]
     assert len(rows) == lib.rrt_interleaved_row_count(height, group_rows, first_group, group_stride)
     return np.asarray(rows, np.int64)
+
+
+def quantise_pack_device(rgb_ptr, depth_ptr, n_pixels, rgbd_ptr, stream=None):
+    """A rendered share in HBM -> 4 bytes r g b d per pixel, the reference's `(c * 255.0) as u8` (framebuffer.rs:96-130)."""
+    check(lib.rrt_quantise_pack_device(rgb_ptr, depth_ptr, n_pixels, rgbd_ptr, stream))
+
+
+def assemble_frame_device(parts_ptr, world, rows_max, width, height, row_group, rgb_ptr, depth_ptr, stream=None):
+    """The ranks' packed shares -> the frame's P6 / P5 payloads in image order (FrameBuffer::combine_rows on rank 0)."""
+    check(lib.rrt_assemble_frame_device(parts_ptr, world, rows_max, width, height, row_group, rgb_ptr, depth_ptr, stream))
 
 
 def last_error():

@@ -57,6 +57,7 @@ struct IndexHeader {
     uint32_t error;                 // 1: more dense records than records (internal error)
     uint32_t trim_steps;            // k_choose_dense: faces moved while trimming the boxes (RRT_INDEX_INFO prints it)
     uint32_t pad;
+    uint32_t choose_ticks[4];       // k_choose_dense: 100 MHz ticks spent loading the samples / sorting / trimming / in all (RRT_INDEX_INFO)
     unsigned long long crowding_sum;  // k_finish_header: sum over the dense cells of count^2
 };
 
@@ -139,6 +140,10 @@ struct BatchTraceArgs {
 void launch_batch_trace(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream);
 void launch_batch_shadow(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream);
 // rays given explicitly (rrt_raytrace): fills level-0 ray buffers from host-style [n][3] arrays
+// multi-GPU frames: a share quantised and packed for the wire, the shares put together on rank 0 (kernels.hip)
+void launch_quantise_pack(const float *rgb, const float *depth, uint32_t n, uint8_t *out, hipStream_t stream);
+void launch_assemble_frame(const uint8_t *parts, uint32_t world, uint32_t rows_max, uint32_t width, uint32_t height, uint32_t row_group, uint8_t *rgb,
+                           uint8_t *depth, hipStream_t stream);
 void launch_load_rays(const float *origins, const float *directions, uint32_t n, LevelBuffers lv, hipStream_t stream);
 
 }  // namespace rrt

@@ -647,6 +647,53 @@ __global__ void k_load_rays(const float *origins, const float *directions, uint3
     lv.ray_d[i] = make_float4(directions[i * 3], directions[i * 3 + 1], directions[i * 3 + 2], 0.0f);
 }
 
+// ---- what a rank sends to rank 0, and what rank 0 makes of it (multi-GPU frames) -------------------------
+// framebuffer.rs:105-107,124: `(c * 255.0) as u8`, Rust's saturating cast (NaN -> 0)
+__device__ __forceinline__ uint8_t quantise_u8(float v) {
+    const float f = v * 255.0f;
+    return !(f > 0.0f) ? (uint8_t)0 : (f >= 255.0f ? (uint8_t)255 : (uint8_t)f);
+}
+// a share's pixels as the reference would finally write them (P6 + P5 payloads), 4 bytes r g b d per pixel instead of 20
+__global__ void k_quantise_pack(const float *rgb, const float *depth, uint32_t n, uchar4 *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = make_uchar4(quantise_u8(rgb[3 * (size_t)i]), quantise_u8(rgb[3 * (size_t)i + 1]), quantise_u8(rgb[3 * (size_t)i + 2]), quantise_u8(depth[i]));
+}
+// the ranks' packed shares [world][rows_max][width] -> the frame's P6 and P5 payloads in image order.  Which rank rendered
+// image row y and as which of its rows follows from the split alone (rrt_render_interleaved_device: groups of row_group rows
+// dealt round-robin; row_group = 0: the contiguous bands of camera.rs:14-31, height / world rows each, the rest on the last).
+__global__ void k_assemble_frame(const uchar4 *parts, uint32_t world, uint32_t rows_max, uint32_t width, uint32_t height, uint32_t row_group,
+                                 uint8_t *rgb, uint8_t *depth) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    uint32_t rank, local;
+    if (row_group) {
+        const uint32_t g = y / row_group;
+        rank = g % world;
+        local = (g / world) * row_group + y % row_group;
+    } else {
+        const uint32_t per = height / world;
+        rank = per ? min(y / per, world - 1u) : world - 1u;
+        local = y - rank * per;
+    }
+    const uchar4 v = parts[((size_t)rank * rows_max + local) * width + x];
+    const size_t at = (size_t)y * width + x;
+    rgb[3 * at] = v.x;
+    rgb[3 * at + 1] = v.y;
+    rgb[3 * at + 2] = v.z;
+    depth[at] = v.w;
+}
+void launch_quantise_pack(const float *rgb, const float *depth, uint32_t n, uint8_t *out, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_quantise_pack, dim3((n + 255u) / 256u), dim3(256), 0, stream, rgb, depth, n, reinterpret_cast<uchar4 *>(out));
+}
+void launch_assemble_frame(const uint8_t *parts, uint32_t world, uint32_t rows_max, uint32_t width, uint32_t height, uint32_t row_group, uint8_t *rgb,
+                           uint8_t *depth, hipStream_t stream) {
+    if (width == 0 || height == 0) return;
+    hipLaunchKernelGGL(k_assemble_frame, dim3((width + 255u) / 256u, height), dim3(256), 0, stream, reinterpret_cast<const uchar4 *>(parts), world, rows_max,
+                       width, height, row_group, rgb, depth);
+}
+
 static inline uint32_t blocks_for(uint32_t n) { return (n + RRT_BLOCK - 1) / RRT_BLOCK; }
 
 void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream) {

@@ -384,6 +384,8 @@ __global__ __launch_bounds__(PH_CHOOSE_THREADS) void k_choose_dense(const float4
     const uint32_t tid = threadIdx.x;
     const uint32_t n_samples = min(n, (uint32_t)PH_SAMPLES), stride = max(1u, n / n_samples);
     uint32_t parity = 0;
+    const uint64_t t_start = wall_clock64();
+    uint64_t t_loaded = t_start, t_sort = 0, t_trim = 0, t_mark;
     // sample tid + j * threads lives in this thread's registers
     float px[PH_PER_THREAD], py[PH_PER_THREAD], pz[PH_PER_THREAD];
     uint32_t alive = 0;  // bit j
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(PH_CHOOSE_THREADS) void k_choose_dense(const float4
     }
     cnt[0] = (uint32_t)__popc(alive);
     block_sum6(cnt, s_part, parity);
+    t_loaded = wall_clock64();
     if (cnt[0] == 0) {  // no finite position at all: one sample at the origin
         if (tid == 0) {
             px[0] = py[0] = pz[0] = 0.0f;
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(PH_CHOOSE_THREADS) void k_choose_dense(const float4
     const float inv = inv_dcell;  // (what the records are filed with)
     while (n_grids < max_grids && left > 0 && (n_grids == 0 || (uint64_t)left * 100u >= (uint64_t)all * 3u)) {
         // quantiles of the samples still without a grid: the three axes through one bitonic sort, the other samples at +inf
+        t_mark = wall_clock64();
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < PH_PER_THREAD; j++) {
@@ -457,6 +461,8 @@ __global__ __launch_bounds__(PH_CHOOSE_THREADS) void k_choose_dense(const float4
                 hi[a] = (double)s_v[a][(uint32_t)(0.998 * (double)m)];
             }
         }
+        t_sort += wall_clock64() - t_mark;
+        t_mark = wall_clock64();
         auto cells_of = [&](int a) { return fmax(1.0, ceil((hi[a] - lo[a]) / (double)cell) + 4.0); };
         double nc[3] = {cells_of(0), cells_of(1), cells_of(2)};  // cells along each axis of the box as it stands
         for (int it = 0; it < 400 && nc[0] * nc[1] * nc[2] > budget; it++) {
@@ -494,20 +500,31 @@ __global__ __launch_bounds__(PH_CHOOSE_THREADS) void k_choose_dense(const float4
                 loss[3] += a1 & 1023u, loss[4] += (a1 >> 10) & 1023u, loss[5] += a1 >> 20;
             }
             parity ^= 1u;
+            // the face that loses the fewest samples (the first of equals), among the axes that are not thin already; written
+            // with constant indices only: an array indexed by `best` would live in scratch memory, a few microseconds per step
             int best = -1;
+            uint32_t best_loss = 0;
 #pragma unroll
             for (int f = 0; f < 6; f++) {
                 if (nc[f / 2] <= 8.0) continue;  // an axis this thin is not what makes the grid large
-                if (best < 0 || loss[f] < loss[best]) best = f;
+                if (best < 0 || loss[f] < best_loss) {
+                    best = f;
+                    best_loss = loss[f];
+                }
             }
             if (best < 0) break;
-            if (best & 1)
-                hi[best / 2] = cut[best];
-            else
-                lo[best / 2] = cut[best];
-            nc[best / 2] = cells_of(best / 2);
+#pragma unroll
+            for (int f = 0; f < 6; f++)
+                if (f == best) {
+                    if (f & 1)
+                        hi[f / 2] = cut[f];
+                    else
+                        lo[f / 2] = cut[f];
+                    nc[f / 2] = cells_of(f / 2);
+                }
             trim_steps++;
         }
+        t_trim += wall_clock64() - t_mark;
         double dims[3];
         for (int a = 0; a < 3; a++) {
             lo[a] -= 2.0 * (double)cell;
@@ -551,6 +568,8 @@ __global__ __launch_bounds__(PH_CHOOSE_THREADS) void k_choose_dense(const float4
         H->error = 0;
         H->trim_steps = trim_steps;
         H->pad = 0;
+        H->choose_ticks[0] = (uint32_t)(t_loaded - t_start), H->choose_ticks[1] = (uint32_t)t_sort, H->choose_ticks[2] = (uint32_t)t_trim;
+        H->choose_ticks[3] = (uint32_t)(wall_clock64() - t_start);
         H->crowding_sum = 0;
     }
 }
@@ -1003,8 +1022,9 @@ static int finish_index(rrt_scene *s, int which) {
     X.table_size = H.table_size;
     X.crowding = (double)H.crowding_sum / (double)n;
     if (getenv("RRT_INDEX_INFO")) {
-        fprintf(stderr, "[index %d] %u records: %u in %u dense grids (cell %.3g, %u cells), %u outliers in %u hash cells (table %u); crowding %.1f; %u trimming steps\n",
-                which, n, X.n_dense, X.n_grids, s->params.gather_half_width, X.dense_cells, n - X.n_dense, H.out_cells, H.table_size, X.crowding, H.trim_steps);
+        fprintf(stderr, "[index %d] %u records: %u in %u dense grids (cell %.3g, %u cells), %u outliers in %u hash cells (table %u); crowding %.1f; %u trimming steps (choice: load %.1f, sort %.1f, trim %.1f, all %.1f us)\n",
+                which, n, X.n_dense, X.n_grids, s->params.gather_half_width, X.dense_cells, n - X.n_dense, H.out_cells, H.table_size, X.crowding, H.trim_steps,
+                H.choose_ticks[0] * 0.01, H.choose_ticks[1] * 0.01, H.choose_ticks[2] * 0.01, H.choose_ticks[3] * 0.01);
         for (uint32_t g = 0; g < X.n_grids; g++)
             fprintf(stderr, "[index %d]   grid %u: %u x %u x %u from %.9g %.9g %.9g\n", which, g, X.grids[g].nx, X.grids[g].ny, X.grids[g].nz, X.grids[g].lo_x,
                     X.grids[g].lo_y, X.grids[g].lo_z);

@@ -1421,6 +1421,35 @@ int rrt_render_interleaved_device(rrt_scene *s, const rrt_camera *cam, uint32_t 
     return render_rays(s, &dc, 0, (uint32_t)n, nullptr, nullptr, rgb_dev, depth_dev, object_id_dev, (hipStream_t)hip_stream);
 }
 
+int rrt_quantise_pack_device(const float *rgb_dev, const float *depth_dev, size_t n_pixels, uint8_t *rgbd_dev, void *hip_stream) {
+    if (n_pixels == 0) return RRT_OK;
+    if (!rgb_dev || !depth_dev || !rgbd_dev) return fail(RRT_ERR_INVALID, "null argument");
+    if (n_pixels >= (1ull << 31)) return fail(RRT_ERR_LIMIT, "more than 2^31 pixels in one share");
+    launch_quantise_pack(rgb_dev, depth_dev, (uint32_t)n_pixels, rgbd_dev, (hipStream_t)hip_stream);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
+int rrt_assemble_frame_device(const uint8_t *parts_dev, uint32_t world, uint32_t rows_max, uint32_t width, uint32_t height, uint32_t row_group,
+                              uint8_t *rgb_dev, uint8_t *depth_dev, void *hip_stream) {
+    if (!parts_dev || !rgb_dev || !depth_dev) return fail(RRT_ERR_INVALID, "null argument");
+    if (world == 0 || height >= 65536u) return fail(RRT_ERR_INVALID, "bad world size or frame height");
+    // every rank's share must fit the rows_max rows its segment holds
+    for (uint32_t r = 0; r < world; r++) {
+        uint32_t rows;
+        if (row_group) {
+            rows = rrt_interleaved_row_count(height, row_group, r, world);
+        } else {
+            const uint32_t per = height / world;
+            rows = r + 1 == world ? height - per * (world - 1) : per;
+        }
+        if (rows > rows_max) return fail(RRT_ERR_INVALID, "rows_max is smaller than a rank's share of the frame");
+    }
+    launch_assemble_frame(parts_dev, world, rows_max, width, height, row_group, rgb_dev, depth_dev, (hipStream_t)hip_stream);
+    RRT_HIP(hipGetLastError());
+    return RRT_OK;
+}
+
 int rrt_render(rrt_scene *s, const rrt_camera *cam, uint32_t y0, uint32_t y1, float *rgb, float *depth, uint32_t *object_id) {
     if (!s || !cam) return fail(RRT_ERR_INVALID, "null argument");
     if (int rc_dev = use_scene_device(s)) return rc_dev;

@@ -200,17 +200,26 @@ def photon_pass(scene, exchange, n_lights, photons_per_light, caustic_photons_pe
 
 
 class FrameGather:
-    """Row shares of one frame, rendered by every rank into ONE packed buffer (rgb | depth | id planes over `rows_max` rows,
-    so that the frame needs a single collective) and gathered to rank 0, which puts the rows back in image order.
+    """Row shares of one frame, rendered by every rank into ONE packed buffer and gathered to rank 0, which puts the rows back
+    in image order.
+
+    wire = "u8" (what bench.py uses): a rank sends what the reference finally writes, FrameBuffer::write_rgb_file /
+    write_depth_file's `(c * 255.0) as u8` (framebuffer.rs:96-130) — 4 bytes r g b d per pixel, quantised and packed on the
+    device (rrt_quantise_pack_device), 33 MB for a 4K frame; rank 0 turns the gathered shares into the P6 / P5 payloads with
+    ONE kernel that knows the split (rrt_assemble_frame_device), no index arrays, no per-plane copies.
+    wire = "f32" (tests: bit-exact frames with object ids): rgb | depth | id planes of f32, 20 bytes per pixel.
 
     interleave > 0: rank r renders the 8 x interleave row groups r, r + world, ... (rrt_render_interleaved_device);
     interleave == 0: contiguous bands (camera.rs:14-31)."""
 
-    def __init__(self, rrt, cam, rank, world, dist, device, interleave=8, buffers=2, stage_host=False):
+    def __init__(self, rrt, cam, rank, world, dist, device, interleave=8, buffers=2, stage_host=False, wire="f32"):
         self.rrt, self.cam, self.rank, self.world, self.dist, self.device = rrt, cam, rank, world, dist, device
         self.interleave = interleave
+        assert wire in ("f32", "u8")
+        self.wire = wire
         # stage_host: the collective runs on host copies (gloo rehearsals with several ranks on one GPU)
         self.stage_host = bool(stage_host) and world > 1
+        self.on_gpu = str(device).startswith("cuda")
         cdev = "cpu" if self.stage_host else device
         H, W = cam.height, cam.width
         if interleave:
@@ -225,28 +234,40 @@ class FrameGather:
         self.plane = self.rows_max * W  # elements per plane
         # per buffer: [5][rows_max][W] 4-byte words: rgb as 3 planes' worth of interleaved floats, then depth, then ids
         self.local = [torch.empty(5 * self.plane, dtype=torch.float32, device=device) for _ in range(buffers)]
-        self.stage = [torch.empty(5 * self.plane, dtype=torch.float32, device="cpu") if self.stage_host else None for _ in range(buffers)]
-        self.parts = [torch.empty((world, 5 * self.plane), dtype=torch.float32, device=cdev) if rank == 0 and world > 1 else None for _ in range(buffers)]
+        words = 5 * self.plane if wire == "f32" else self.plane  # 4-byte words a rank sends per frame
+        wdtype = torch.float32 if wire == "f32" else torch.uint8
+        wlen = words if wire == "f32" else 4 * words
+        self.wire_bytes = 4 * words
+        # u8: the share packed r g b d per pixel (the f32 wire sends `local` itself)
+        self.packed = [torch.empty(wlen, dtype=torch.uint8, device=device) if wire == "u8" else None for _ in range(buffers)]
+        self.stage = [torch.empty(wlen, dtype=wdtype, device="cpu") if self.stage_host else None for _ in range(buffers)]
+        self.parts = [torch.empty((world, wlen), dtype=wdtype, device=cdev) if rank == 0 and world > 1 else None for _ in range(buffers)]
         self.pending = [None] * buffers
         if rank == 0:
-            H_rank = torch.empty(H, dtype=torch.int64)   # which rank rendered image row y, and which of its rows it is
-            H_row = torch.empty(H, dtype=torch.int64)
-            for r, rr in enumerate(rows):
-                H_rank[torch.as_tensor(rr)] = r
-                H_row[torch.as_tensor(rr)] = torch.arange(len(rr))
-            self.row_rank, self.row_local = H_rank.to(cdev), H_row.to(cdev)
-            self.frame_rgb = torch.empty((H, W, 3), dtype=torch.float32, device=cdev)
-            self.frame_depth = torch.empty((H, W), dtype=torch.float32, device=cdev)
-            self.frame_ids = torch.empty((H, W), dtype=torch.int32, device=cdev)
+            if wire == "f32" or world == 1:
+                H_rank = torch.empty(H, dtype=torch.int64)   # which rank rendered image row y, and which of its rows it is
+                H_row = torch.empty(H, dtype=torch.int64)
+                for r, rr in enumerate(rows):
+                    H_rank[torch.as_tensor(rr)] = r
+                    H_row[torch.as_tensor(rr)] = torch.arange(len(rr))
+                self.row_rank, self.row_local = H_rank.to(cdev), H_row.to(cdev)
+                self.frame_rgb = torch.empty((H, W, 3), dtype=torch.float32, device=cdev)
+                self.frame_depth = torch.empty((H, W), dtype=torch.float32, device=cdev)
+                self.frame_ids = torch.empty((H, W), dtype=torch.int32, device=cdev)
+            if wire == "u8":  # the frame as FrameBuffer::write_rgb_file / write_depth_file would write it
+                self.frame_rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=device)
+                self.frame_depth8 = torch.empty((H, W), dtype=torch.uint8, device=device)
+                self.parts_dev = [torch.empty((world, wlen), dtype=torch.uint8, device=device) if self.stage_host else None for _ in range(buffers)]
 
     def pointers(self, k):
-        if self.world == 1:  # one rank renders straight into the frame
+        if self.world == 1 and self.wire == "f32":  # one rank renders straight into the frame
             return self.frame_rgb.data_ptr(), self.frame_depth.data_ptr(), self.frame_ids.data_ptr()
         base = self.local[k].data_ptr()
         return base, base + 3 * self.plane * 4, base + 4 * self.plane * 4
 
     def render(self, scene, cam, k, stream=None):
-        """This rank's share of the frame into buffer k (returns when the share is rendered)."""
+        """This rank's share of the frame into buffer k (returns when the share is rendered; the u8 wire's packing kernel
+        is queued behind it on the same stream)."""
         rgb, depth, ids = self.pointers(k)
         if self.n_rows[self.rank] == 0:
             return
@@ -255,12 +276,17 @@ class FrameGather:
         else:
             y0, y1 = row_band(cam.height, self.rank, self.world)
             scene.render_device(cam, y0, y1, rgb, depth, ids, stream)
+        if self.wire == "u8":
+            self.rrt.quantise_pack_device(rgb, depth, self.n_rows[self.rank] * cam.width, self.packed[k].data_ptr(), stream)
+
+    def _send_buffer(self, k):
+        return self.local[k] if self.wire == "f32" else self.packed[k]
 
     def start_gather(self, k):
         """Collective of buffer k (asynchronous: the next frame renders into the other buffer meanwhile)."""
         if self.world > 1:
             outs = list(self.parts[k].unbind(0)) if self.rank == 0 else None
-            src = self.local[k]
+            src = self._send_buffer(k)
             if self.stage_host:
                 self.stage[k].copy_(src)
                 src = self.stage[k]
@@ -272,7 +298,7 @@ class FrameGather:
         if self.pending[k] is not None:
             self.pending[k].wait()
             self.pending[k] = None
-        if str(self.device).startswith("cuda"):
+        if self.on_gpu:
             torch.cuda.synchronize()
 
     def finish(self, k):
@@ -282,8 +308,23 @@ class FrameGather:
             self.pending[k] = None
         if self.rank != 0:
             return None
+        W, H = self.cam.width, self.cam.height
+        if self.wire == "u8":
+            parts = self.parts[k] if self.world > 1 else self.packed[k].view(1, -1)
+            if self.stage_host:
+                self.parts_dev[k].copy_(parts)
+                parts = self.parts_dev[k]
+            if self.on_gpu:  # one kernel; the split tells it where every row lies
+                self.rrt.assemble_frame_device(parts.data_ptr(), self.world, self.rows_max, W, H, self.interleave, self.frame_rgb8.data_ptr(),
+                                               self.frame_depth8.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            else:  # host tensors standing in for the device (the gloo tests): the same assembly with torch indexing
+                px = parts.view(self.world, self.rows_max, W, 4)
+                idx_rank, idx_row = self._row_index()
+                rows = px[idx_rank, idx_row]
+                self.frame_rgb8.copy_(rows[..., :3])
+                self.frame_depth8.copy_(rows[..., 3])
+            return self.frame_rgb8, self.frame_depth8, None
         if self.world > 1:
-            W = self.cam.width
             src = self.parts[k]  # [world][5 * plane]: strided views of the three planes, gathered row by row in one pass each
             rgb = src[:, : 3 * self.plane].unflatten(1, (self.rows_max, W * 3))
             depth = src[:, 3 * self.plane: 4 * self.plane].unflatten(1, (self.rows_max, W))
@@ -293,6 +334,14 @@ class FrameGather:
             self.frame_ids.view(torch.float32).copy_(ids[self.row_rank, self.row_local])
         return self.frame_rgb, self.frame_depth, self.frame_ids
 
+    def _row_index(self):
+        H = self.cam.height
+        idx_rank, idx_row = torch.empty(H, dtype=torch.int64), torch.empty(H, dtype=torch.int64)
+        for r, rr in enumerate(self.rows):
+            idx_rank[torch.as_tensor(rr)] = r
+            idx_row[torch.as_tensor(rr)] = torch.arange(len(rr))
+        return idx_rank, idx_row
+
     def bytes_per_frame(self):
         """Bytes rank 0 receives per frame from the other ranks."""
-        return (self.world - 1) * 5 * self.plane * 4
+        return (self.world - 1) * self.wire_bytes

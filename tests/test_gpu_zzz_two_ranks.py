@@ -12,15 +12,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_equal_one_rank_on_device(repo):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_equal_one_rank_on_device(repo, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(repo, "tools/two_rank_photon_rehearsal.py")]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=repo)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=repo)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert "two ranks == one rank" in out.stdout and "bit for bit" in out.stdout
+    assert "%d ranks == one rank" % world in out.stdout and "bit for bit" in out.stdout
 
 
 def test_bench_with_two_ranks_measures_both_splits(repo):
@@ -42,6 +43,7 @@ def test_bench_with_two_ranks_measures_both_splits(repo):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 4
     assert j["collective_ms"] >= 0.0 and j["collective_gb_per_s"] is not None
+    assert 0 < j["collective_bytes"] <= 45_000_000   # u8 rgb + depth on the wire: half a 4K frame at 4 bytes per pixel
     assert 15_000_000 < j["config"]["rays_per_frame"] < 16_500_000          # both shares add up to the whole frame
     p = j["extra"]["photon_pass"]
     assert "error" not in p, p
