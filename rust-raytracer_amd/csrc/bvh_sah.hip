@@ -25,6 +25,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "bvh_lbvh.h"
+#include "bvh_quant.h"
 #include "runtime.h"
 
 namespace rrt {
@@ -643,8 +644,45 @@ __global__ __launch_bounds__(kBlock) void k_sah_emit(const Node *nodes, uint32_t
 
 // positions: host [n][3][3].  Outputs as build_bvh (bvh_build.cpp).  n > kLeafMax.  RRT_ERR_UNSUPPORTED_INPUT (returned as
 // +1, not an rrt error code) = a coordinate is not finite: the caller uses the host builder, whose "wild mesh" rules apply.
+namespace {
+// the builder's device arrays: they outlive the build itself so that whoever called it can go on from them on the device
+struct SahBuffers {
+    DBuf<float> d_pos, d_tb, d_cen;
+    DBuf<uint32_t> d_order, d_order2, d_nodeof, d_nodeof2, d_flag, d_rank, d_bins, d_word, d_inner, d_index;
+    DBuf<Node> d_nodes;
+    DBuf<BvhNode> d_out;
+    DBuf<char> d_temp;
+    // results
+    const uint32_t *order = nullptr;  // triangle order (one of d_order / d_order2)
+    uint32_t n_inner = 0, levels = 0;
+};
+int sah_build(const float *positions, uint32_t n, SahBuffers &B, float *device_ms);
+}  // namespace
+
 int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
                          float *device_ms) {
+    SahBuffers B;
+    int rc = sah_build(positions, n, B, device_ms);
+    if (rc) return rc;
+    const bool timing = getenv("RRT_LBVH_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    nodes.resize(B.n_inner);
+    order.resize(n);
+    RRT_HIP(hipMemcpy(nodes.data(), B.d_out.p, (size_t)B.n_inner * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    RRT_HIP(hipMemcpy(order.data(), B.order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    max_depth = B.levels;
+    if (timing) fprintf(stderr, "[sah] %-28s %8.2f ms\n", "download", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+    return RRT_OK;
+}
+
+namespace {
+int sah_build(const float *positions, uint32_t n, SahBuffers &B, float *device_ms) {
+    DBuf<float> &d_pos = B.d_pos, &d_tb = B.d_tb, &d_cen = B.d_cen;
+    DBuf<uint32_t> &d_order = B.d_order, &d_order2 = B.d_order2, &d_nodeof = B.d_nodeof, &d_nodeof2 = B.d_nodeof2, &d_flag = B.d_flag, &d_rank = B.d_rank,
+                   &d_bins = B.d_bins, &d_word = B.d_word, &d_inner = B.d_inner, &d_index = B.d_index;
+    DBuf<Node> &d_nodes = B.d_nodes;
+    DBuf<BvhNode> &d_out = B.d_out;
+    DBuf<char> &d_temp = B.d_temp;
     if (n <= kLeafMax) return fail(RRT_ERR_INVALID, "device BVH build needs more than 4 triangles");
     if (n >= (1u << 27)) return fail(RRT_ERR_LIMIT, "more than 2^27 triangles in one mesh");
     int count = 0;
@@ -660,11 +698,6 @@ int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_
     const uint32_t capacity = 4 * n + 64;      // node records: fewer than 2n in the tree; k_sah_small reserves 2 cnt - 2 per subtree and leaves some unused
     const uint32_t bin_slots = n / 16 + 64;    // nodes of one level: the children of nodes of more than kSmall triangles, so fewer than
                                                // 2 n / 65; twice that is reserved (a wider level is refused, not overrun)
-    DBuf<float> d_pos, d_tb, d_cen;
-    DBuf<uint32_t> d_order, d_order2, d_nodeof, d_nodeof2, d_flag, d_rank, d_bins, d_word, d_inner, d_index;
-    DBuf<Node> d_nodes;
-    DBuf<BvhNode> d_out;
-    DBuf<char> d_temp;
     int rc;
     if ((rc = d_pos.ensure((size_t)n * 9)) || (rc = d_tb.ensure((size_t)n * 6)) || (rc = d_cen.ensure((size_t)n * 3)) || (rc = d_order.ensure(n)) ||
         (rc = d_order2.ensure(n)) || (rc = d_nodeof.ensure(n)) || (rc = d_nodeof2.ensure(n)) || (rc = d_flag.ensure(n + 1)) || (rc = d_rank.ensure(n + 1)) ||
@@ -770,13 +803,179 @@ int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_
                  n_inner, total, levels);
         return fail(RRT_ERR_DEVICE, what);
     }
-    nodes.resize(n_inner);
-    order.resize(n);
-    RRT_HIP(hipMemcpy(nodes.data(), d_out.p, (size_t)n_inner * sizeof(BvhNode), hipMemcpyDeviceToHost));
-    RRT_HIP(hipMemcpy(order.data(), order_a, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    max_depth = levels;
-    lap("download");
+    B.order = order_a;
+    B.n_inner = n_inner;
+    B.levels = levels;
+    return RRT_OK;
+}
+}  // namespace
+
+// ---- the rest of a mesh's flattening on the device (pre_render without host stages) -----------------
+// After the build the tree, the triangle order and the positions are in HBM; the traversal's arrays are made from them
+// there: the hull of the tree's boxes (-> the mesh's 16-bit grid, a few words read back), the four-wide collapse level by level
+// (bvh_quant.h's own functions: the host's bytes), the triangle records.  Nothing of the mesh goes back to the host but the
+// grid and the node count.
+namespace {
+// hull of every child box of the tree: order-preserving words under atomicMin / atomicMax; acc[6]: wild
+__global__ __launch_bounds__(kBlock) void k_tree_hull(const BvhNode *nodes, uint32_t n_nodes, uint32_t *acc) {
+    __shared__ uint32_t s_acc[7];
+    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x >= 3 && threadIdx.x < 7) s_acc[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_nodes) {
+        const float lim = 1152921504606846976.0f;  // 2^60
+        const BvhNode n = nodes[i];
+        bool wild = false;
+        for (int a = 0; a < 3; a++) {
+            const float4 b = bq::box_axis(n, a);
+            const float v[4] = {b.x, b.y, b.z, b.w};
+            for (int c = 0; c < 2; c++) {
+                const float l = v[c], h = v[2 + c];
+                if (l > h) continue;  // empty child
+                if (!(fabsf(l) < lim) || !(fabsf(h) < lim)) wild = true;
+                if (l == l) atomicMin(&s_acc[a], ordered(l));      // (std::min(lo, l) never takes a NaN)
+                if (h == h) atomicMax(&s_acc[3 + a], ordered(h));
+            }
+            if (b.x != b.x || b.y != b.y || b.z != b.z || b.w != b.w) wild = true;
+        }
+        if (wild) s_acc[6] = 1u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&acc[threadIdx.x], s_acc[threadIdx.x]);
+    if (threadIdx.x >= 3 && threadIdx.x < 6) atomicMax(&acc[threadIdx.x], s_acc[threadIdx.x]);
+    if (threadIdx.x == 6 && s_acc[6]) acc[6] = 1u;
+}
+// One level of the collapse.  Work item i: output node dst0 + i stands for BVH2 node src[i].
+//   count: how many inner children it will have (-> exclusive scan = where its children's indices start)
+//   emit : the node itself, its inner children as the next level's work items, their stack need
+__global__ void k_collapse_count(const BvhNode *nodes, const uint32_t *src, uint32_t n_items, uint32_t wild, uint32_t *count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    bq::Slot sl[4];
+    const int m = bq::collapse(nodes, src[i], wild != 0u, sl);
+    uint32_t inner = 0;
+    for (int k = 0; k < m; k++) inner += sl[k].ref >= 0 ? 1u : 0u;
+    count[i] = inner;
+}
+__global__ void k_collapse_emit(const BvhNode *nodes, const uint32_t *src, const uint32_t *need, uint32_t n_items, bq::Grid grid, const uint32_t *offset,
+                                uint32_t dst0, uint32_t next0, uint32_t capacity, BvhNodeQ *out, uint32_t *next_src, uint32_t *next_need, uint32_t *stack_need) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    bq::Slot sl[4];
+    const int m = bq::collapse(nodes, src[i], grid.wild != 0u, sl);
+    const uint32_t below = need[i] + (m > 0 ? (uint32_t)m - 1u : 0u);  // stack entries while below this node
+    atomicMax(stack_need, below);
+    const uint32_t first = next0 + offset[i];
+    if (dst0 + i < capacity) out[dst0 + i] = bq::encode(grid, sl, m, first);
+    uint32_t rank = 0;
+    for (int k = 0; k < m; k++)
+        if (sl[k].ref >= 0) {
+            next_src[offset[i] + rank] = (uint32_t)sl[k].ref;
+            next_need[offset[i] + rank] = below;
+            rank++;
+        }
+}
+// what Triangle::get_plane caches (triangle_object.rs:51-52, 85-89; plane_object.rs:37), in BVH order
+__global__ void k_tri_records(const float *pos, const uint32_t *order, uint32_t n, TriHot *tris, uint32_t *tri_index) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t src = order[k];
+    const float *p = pos + (size_t)src * 9;
+    const f3 a = mk3(p[0], p[1], p[2]), b = mk3(p[3], p[4], p[5]), c = mk3(p[6], p[7], p[8]);
+    const f3 ab = b - a, bc = c - b;
+    const f3 nrm = norm3(cross3(ab, bc));
+    const float d = -dot3(nrm, a);
+    TriHot t;
+    t.a_nx = make_float4(a.x, a.y, a.z, nrm.x);
+    t.b_ny = make_float4(b.x, b.y, b.z, nrm.y);
+    t.c_nz = make_float4(c.x, c.y, c.z, nrm.z);
+    t.d_pad = make_float4(d, 0.0f, 0.0f, 0.0f);
+    tris[k] = t;
+    tri_index[k] = src;
+}
+}  // namespace
+
+int build_mesh_device_sah(const float *positions, uint32_t n, MeshInfo &mi, DeviceMesh &M, uint32_t &stack_need, float *device_ms) {
+    SahBuffers B;
+    int rc = sah_build(positions, n, B, device_ms);
+    if (rc) return rc;
+    const bool timing = getenv("RRT_LBVH_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[flatten, device] %-17s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count());
+        T0 = t;
+    };
+    const uint32_t n_inner = B.n_inner;
+    // triangle records: independent of everything below
+    if ((rc = M.tris.ensure(n)) || (rc = M.tri_index.ensure(n))) return rc;
+    hipLaunchKernelGGL(k_tri_records, grid_for(n), dim3(kBlock), 0, nullptr, B.d_pos.p, B.order, n, M.tris.p, M.tri_index.p);
+    M.n_tris = n;
+    // the grid
+    uint32_t acc[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};  // [7]: stack need
+    DBuf<uint32_t> d_acc;
+    if ((rc = d_acc.ensure(8))) return rc;
+    RRT_HIP(hipMemcpy(d_acc.p, acc, sizeof(acc), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_tree_hull, grid_for(n_inner), dim3(kBlock), 0, nullptr, B.d_out.p, n_inner, d_acc.p);
+    RRT_HIP(hipGetLastError());
+    RRT_HIP(hipMemcpy(acc, d_acc.p, sizeof(acc), hipMemcpyDeviceToHost));
+    bq::Hull hull;
+    for (int a = 0; a < 3; a++) {
+        hull.lo[a] = acc[a] == 0xFFFFFFFFu ? INFINITY : unordered(acc[a]);
+        hull.hi[a] = acc[3 + a] == 0u ? -INFINITY : unordered(acc[3 + a]);
+    }
+    hull.wild = acc[6] != 0u;
+    bq::make_grid(hull, mi);
+    const bq::Grid grid = bq::grid_of(mi);
+    lap("triangles + grid");
+    // the collapse, a level per round: every output node has at least two children and every BVH2 node stands for at most
+    // one output node, so there are at most n_inner of them
+    DBuf<uint32_t> src[2], need[2], count, offset;
+    DBuf<char> temp;
+    if ((rc = M.qnodes.ensure(n_inner)) || (rc = src[0].ensure(n_inner)) || (rc = src[1].ensure(n_inner)) || (rc = need[0].ensure(n_inner)) ||
+        (rc = need[1].ensure(n_inner)) || (rc = count.ensure(n_inner + 1)) || (rc = offset.ensure(n_inner + 1)))
+        return rc;
+    size_t scan_bytes = 0;
+    RRT_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, count.p, offset.p, 0u, (size_t)n_inner + 1, rocprim::plus<uint32_t>(), nullptr));
+    if ((rc = temp.ensure(std::max<size_t>(scan_bytes, 1)))) return rc;
+    const uint32_t zero[2] = {0u, 0u};
+    RRT_HIP(hipMemcpy(src[0].p, zero, sizeof(uint32_t), hipMemcpyHostToDevice));   // the root stands for BVH2 node 0 ...
+    RRT_HIP(hipMemcpy(need[0].p, zero, sizeof(uint32_t), hipMemcpyHostToDevice));  // ... and is reached with an empty stack
+    uint32_t dst0 = 0, items = 1, rounds = 0;
+    int cur = 0;
+    while (items) {
+        if (dst0 + items > n_inner || ++rounds > 4096) return fail(RRT_ERR_DEVICE, "device BVH collapse produced an invalid tree (internal error)");
+        hipLaunchKernelGGL(k_collapse_count, grid_for(items), dim3(kBlock), 0, nullptr, B.d_out.p, src[cur].p, items, grid.wild, count.p);
+        // (the scan runs over items + 1 entries: offset[items] = the next level's size; count[items] itself is not read)
+        RRT_HIP(rocprim::exclusive_scan(temp.p, scan_bytes, count.p, offset.p, 0u, (size_t)items + 1, rocprim::plus<uint32_t>(), nullptr));
+        hipLaunchKernelGGL(k_collapse_emit, grid_for(items), dim3(kBlock), 0, nullptr, B.d_out.p, src[cur].p, need[cur].p, items, grid, offset.p, dst0,
+                           dst0 + items, n_inner, M.qnodes.p, src[cur ^ 1].p, need[cur ^ 1].p, d_acc.p + 7);
+        RRT_HIP(hipGetLastError());
+        uint32_t next_items = 0;
+        RRT_HIP(hipMemcpy(&next_items, offset.p + items, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        dst0 += items;
+        items = next_items;
+        cur ^= 1;
+    }
+    uint32_t need_max = 0;
+    RRT_HIP(hipMemcpy(&need_max, d_acc.p + 7, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    M.n_nodes = dst0;
+    stack_need = need_max + 1;  // entries below the current node + one word of slack (quantise_bvh)
+    lap("collapse");
+    if (timing) fprintf(stderr, "[flatten, device] %u four-wide nodes in %u levels, stack need %u\n", dst0, rounds, stack_need);
     return RRT_OK;
 }
 
+}  // namespace rrt
+
+// rrt_scene_create touches one kernel of every translation unit, so that the code objects are loaded before the first
+// rrt_pre_render is timed (HIP loads them on first use: tens of milliseconds per unit)
+namespace rrt {
+void preload_bvh_sah() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_tri_records));
+}
 }  // namespace rrt

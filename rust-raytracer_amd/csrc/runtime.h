@@ -223,6 +223,15 @@ int build_bvh_device(const float *positions, uint32_t n, std::vector<uint32_t> &
 // bvh_sah.hip: the host builder's tree, built on the device.  Returns 1 (not an rrt error) when a coordinate is not finite.
 int build_bvh_device_sah(const float *positions, uint32_t n, std::vector<uint32_t> &order, std::vector<BvhNode> &nodes, uint32_t &max_depth,
                      float *device_ms);
+// bvh_sah.hip: the same build with everything that follows it done on the device as well — the mesh's grid (mi.qbase, qscale,
+// qmag, wild), the four-wide quantised nodes (quantise_bvh's bytes), the triangle records and their original indices stay in HBM
+struct DeviceMesh {
+    DBuf<BvhNodeQ> qnodes;
+    DBuf<TriHot> tris;
+    DBuf<uint32_t> tri_index;
+    uint32_t n_nodes = 0, n_tris = 0;
+};
+int build_mesh_device_sah(const float *positions, uint32_t n, MeshInfo &mi, DeviceMesh &M, uint32_t &stack_need, float *device_ms);
 void drop_render_workers(rrt_scene *s);
 // HIP's current device is per thread (new threads start on device 0): entry points that touch the scene's memory call this
 int use_scene_device(const rrt_scene *s);  // before device data of the scene or its photon maps is rebuilt
