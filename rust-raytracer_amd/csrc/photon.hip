@@ -924,7 +924,7 @@ static double dense_cell_budget(uint32_t n, uint32_t div) {
 static uint32_t dense_div_for(uint64_t regular_records) {
     const char *env = getenv("RRT_DENSE_DIV");  // (read at every build: tools switch it between builds)
     if (env) return (uint32_t)std::min(4, std::max(1, atoi(env)));
-    return regular_records >= RRT_FINE_GRID_RECORDS ? 2u : 1u;
+    return regular_records >= RRT_FINE_GRID_RECORDS ? 3u : 1u;  // (100 M photons, 4K frame: 0.31 s with div 1, 0.16 / 0.13 / 0.14 s with 2 / 3 / 4)
 }
 static uint32_t dense_grids_max() {
     static const char *max_env = getenv("RRT_DENSE_GRIDS_MAX");  // experiments: more than one grid per map
@@ -1283,9 +1283,13 @@ int rrt_photon_build(rrt_scene *s) {
     // Default heavy-query threshold: a query pair on a lit surface reads about 13 x crowding(regular map) candidate records
     // (crowding = occupancy of the dense cell, edge r, a random photon lies in; measured on scene2: 148 candidates per pair
     // at crowding 11); queries 4 x heavier than that are the tail of a launch and get a wave of their own.  A property of
-    // the maps, not of the camera: the same frame always takes the same path.
+    // the maps, not of the camera: the same frame always takes the same path.  Fine grids: crowding is that of the smaller
+    // cells and a lane reads the cube's shell only; measured at 100 M photons (4K frame, cells of r / 3): factors 26 / 52 / 104 /
+    // 208 / 416 give 0.175 / 0.145 / 0.133 / 0.144 / 0.164 s.
     {
-        double t = 52.0 * s->index[0].crowding;
+        const char *f_env = getenv("RRT_HEAVY_FACTOR");  // experiments
+        const double factor = f_env ? atof(f_env) : (s->index[0].div > 1u ? 104.0 : 52.0);
+        double t = factor * s->index[0].crowding;
         s->heavy_auto = t > 4.0e9 ? 0xFFFFFFFEu : std::max<uint32_t>(RRT_HEAVY_THRESHOLD, (uint32_t)t);
     }
     s->maps_built = true;
