@@ -969,12 +969,16 @@ static int enqueue_index(rrt_scene *s, int which) {
     const size_t max_cells = (size_t)budget * div * div * div * max_grids;
     size_t table_cap = 64;  // every record an outlier in a cell of its own, at most half full
     while (table_cap < 2 * (size_t)n) table_cap <<= 1;
-    if ((rc = W.keys.ensure(n)) || (rc = W.keys2.ensure(n)) || (rc = W.idx.ensure(n)) || (rc = W.idx2.ensure(n)) ||
+    // (a sixteenth of slack where a buffer has to grow: the next pass of the same scene stores a few records more or less, and
+    // a reallocation costs more than the build)
+    auto roomy = [](size_t need, size_t have) { return need <= have ? need : need + need / 16 + 1024; };
+    const size_t rn = roomy(n, X.pos.cap), wn = roomy(n, W.keys.cap);
+    if ((rc = W.keys.ensure(wn)) || (rc = W.keys2.ensure(wn)) || (rc = W.idx.ensure(wn)) || (rc = W.idx2.ensure(wn)) ||
         (rc = W.ncell.ensure(PH_CELL_COUNTERS * PH_CELL_COUNTER_STRIDE)) || (rc = W.acc.ensure(512)) || (rc = W.header.ensure(1)) ||
-        (rc = X.pos.ensure(n)) || (rc = X.dir.ensure(n)) || (rc = X.rgb.ensure(n)) || (rc = X.meta.ensure(n)) ||
-        (rc = X.dense_start.ensure(max_cells + 1)) || (rc = X.keys.ensure(table_cap)) || (rc = X.ranges.ensure(table_cap)))
+        (rc = X.pos.ensure(rn)) || (rc = X.dir.ensure(rn)) || (rc = X.rgb.ensure(rn)) || (rc = X.meta.ensure(rn)) ||
+        (rc = X.dense_start.ensure(roomy(max_cells + 1, X.dense_start.cap))) || (rc = X.keys.ensure(table_cap)) || (rc = X.ranges.ensure(table_cap)))
         return rc;
-    if (div > 1 && ((rc = X.agg_dir.ensure(max_cells)) || (rc = X.agg_rgb.ensure(max_cells)))) return rc;
+    if (div > 1 && ((rc = X.agg_dir.ensure(roomy(max_cells, X.agg_dir.cap))) || (rc = X.agg_rgb.ensure(roomy(max_cells, X.agg_rgb.cap))))) return rc;
     IndexHeader *H = W.header.p;
     // canonical order: the records by key (light, pass, photon index, landing, sub-index), over the key bits in use only
     const uint32_t low_bits = std::min<uint32_t>(56u, bit_length(s->meta_or & 0x00FFFFFFFFFFFFFFull)), tag_bits = bit_length(s->meta_or >> 56);
