@@ -359,29 +359,9 @@ __device__ __forceinline__ void walk_begin(Walk &w, const MeshInfo &M, f3 o, f3 
     w.ties = ties;
     w.cur = M.tri_count ? 0 : RRT_WALK_DONE;  // root
 }
-// one node visit of a lane that holds an inner node: four children tested, the nearest hit one next, the others stacked
+// the four children of a fetched node tested, the nearest hit one next, the others stacked
 template <bool PLAIN_STACK>
-__device__ __forceinline__ void walk_node_step(const MeshView &V, Walk &w, LaneStack<PLAIN_STACK> &stack, Counters &cnt) {
-    if ((uint32_t)w.cur >= V.node_count) {
-        cnt.overflow |= 16u;
-        w.cur = RRT_WALK_DONE;
-        return;
-    }
-#if RRT_WALK_STATS == 2
-    RRT_WS_WAVE_COUNT(0);
-#elif RRT_WALK_STATS == 8  // how often do all the lanes that visit a node visit the SAME node
-    {
-        const unsigned long long m_ = __ballot(true), u_ = __ballot(w.cur == __builtin_amdgcn_readfirstlane(w.cur));
-        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m_) - 1u) {
-            cnt.ws[0] += 1ull;
-            cnt.ws[1] += m_ == u_ ? 1ull : 0ull;
-            cnt.ws[2] += (unsigned long long)__popcll(u_);  // lanes on the first lane's node
-        }
-    }
-#endif
-    RRT_WS_TICK(w);  // (inside the loop: a stamp taken on the way out would be sunk behind the loop's exit)
-    RRT_WALK_LOG(0u);
-    const BvhNodeQ N = *reinterpret_cast<const BvhNodeQ *>(reinterpret_cast<const char *>(V.nodes) + ((uint32_t)w.cur << 6));
+__device__ __forceinline__ void walk_node_visit(const BvhNodeQ &N, Walk &w, LaneStack<PLAIN_STACK> &stack, Counters &cnt) {
     int c0 = N.child[0], c1 = N.child[1], c2 = N.child[2], c3 = N.child[3];
     float k0, k1, k2, k3;
     const bool h0 = box_test(N.q[0], N.q[4], N.q[8], w.slabs, w.best, k0);
@@ -405,9 +385,64 @@ __device__ __forceinline__ void walk_node_step(const MeshView &V, Walk &w, LaneS
     else
         w.cur = stack.pop();
 }
-template <bool PLAIN_STACK>
+// one node visit of a lane that holds an inner node: four children tested, the nearest hit one next, the others stacked
+// UNIFORM_MESH: every lane of the wave walks the SAME mesh (the mesh comes from the wave-uniform record loop, not from a
+// lane's own winning record)
+template <bool PLAIN_STACK, bool UNIFORM_MESH>
+__device__ __forceinline__ void walk_node_step(const MeshView &V, Walk &w, LaneStack<PLAIN_STACK> &stack, Counters &cnt) {
+    if ((uint32_t)w.cur >= V.node_count) {
+        cnt.overflow |= 16u;
+        w.cur = RRT_WALK_DONE;
+        return;
+    }
+#if RRT_WALK_STATS == 2
+    RRT_WS_WAVE_COUNT(0);
+#elif RRT_WALK_STATS == 8  // how often do all the lanes that visit a node visit the SAME node
+    {
+        const unsigned long long m_ = __ballot(true), u_ = __ballot(w.cur == __builtin_amdgcn_readfirstlane(w.cur));
+        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m_) - 1u) {
+            cnt.ws[0] += 1ull;
+            cnt.ws[1] += m_ == u_ ? 1ull : 0ull;
+            cnt.ws[2] += (unsigned long long)__popcll(u_);  // lanes on the first lane's node
+        }
+    }
+#endif
+    RRT_WS_TICK(w);  // (inside the loop: a stamp taken on the way out would be sunk behind the loop's exit)
+    RRT_WALK_LOG(0u);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RRT_NO_UNIFORM_NODE)
+    // All lanes that visit a node often visit the SAME one (55 % of the node iterations of the 4K mesh frame: a tile's rays
+    // agree on the upper levels; mirror / glass teapots 44 / 41 %).  Its 64 bytes then come through the scalar cache (one
+    // s_load_dwordx16) instead of 64 x 64 bytes through the vector memory pipeline, and the box tests read them as scalar
+    // operands: 0.937 -> 0.921 ms on the 4K mesh frame (the vector memory pipeline was busy 81 % of the launch).
+    if (UNIFORM_MESH) {
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(w.cur);
+        if (__ballot((uint32_t)w.cur == first) == __ballot(true)) {
+            typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+            // (UNIFORM_MESH: V.nodes is the same in every lane; first < node_count was checked above;
+            //  readfirstlane returns int: widened through uint32_t, or bit 31 of the low half would smear over the high half)
+            const uint64_t base = (uint64_t)reinterpret_cast<uintptr_t>(V.nodes);
+            const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base), b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+            const uint64_t addr = (((uint64_t)b_hi << 32) | (uint64_t)b_lo) + ((uint64_t)first << 6);
+            u32x16 v;
+            // (no "memory" clobber, not volatile: the tree is read-only while the kernel runs, and a clobber would turn every
+            //  later scalar load of scene data into a vector load)
+            asm("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(addr));
+            BvhNodeQ N;
+#pragma unroll
+            for (int k = 0; k < 12; k++) N.q[k] = v[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) N.child[k] = (int32_t)v[12 + k];
+            walk_node_visit(N, w, stack, cnt);
+            return;
+        }
+    }
+#endif
+    const BvhNodeQ N = *reinterpret_cast<const BvhNodeQ *>(reinterpret_cast<const char *>(V.nodes) + ((uint32_t)w.cur << 6));
+    walk_node_visit(N, w, stack, cnt);
+}
+template <bool PLAIN_STACK, bool UNIFORM_MESH>
 __device__ __forceinline__ void walk_nodes(const MeshView &V, Walk &w, LaneStack<PLAIN_STACK> &stack, Counters &cnt) {
-    while (w.cur >= 0) walk_node_step(V, w, stack, cnt);
+    while (w.cur >= 0) walk_node_step<PLAIN_STACK, UNIFORM_MESH>(V, w, stack, cnt);
 }
 // the triangles of the leaf the lane holds (Triangle::intersect for each, the reference's test bit for bit), then the next
 // node off the stack
@@ -450,7 +485,7 @@ __device__ __forceinline__ void walk_leaf(const MeshView &V, Walk &w, LaneStack<
 // PolyMesh::intersect (polymesh_object.rs:216-242): the closest hit of EITHER facing with t >= 0,
 // the lowest triangle index winning exact ties; only hits with t < tmax are reported (callers pass
 // the best distance so far: a farther mesh hit could not win anyway).  Returns the BVH slot.
-template <bool PLAIN_STACK = false>
+template <bool PLAIN_STACK, bool UNIFORM_MESH>
 __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &M, f3 o, f3 d, float tmax, Lds &lds, Counters &cnt,
                                              float &best_t, uint32_t &best_slot, bool &best_entering) {
     const MeshView V = mesh_view(S, M);
@@ -467,7 +502,7 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
     w.ws_last = ws_t0;
 #endif
     while (w.cur != RRT_WALK_DONE) {
-        walk_nodes(V, w, stack, cnt);
+        walk_nodes<PLAIN_STACK, UNIFORM_MESH>(V, w, stack, cnt);
         if (w.cur == RRT_WALK_DONE) break;
         walk_leaf(V, w, stack, cnt);
     }
@@ -574,7 +609,7 @@ __device__ __forceinline__ uint32_t leaf_list(const DevScene &S, const ProgRec &
             uint32_t tri;
             bool ent;
             const MeshInfo &M = S.meshes[r.aux];
-            if (mesh_closest<false>(S, M, o, d, RRT_INF, lds, cnt, t, tri, ent)) {
+            if (mesh_closest<false, true>(S, M, o, d, RRT_INF, lds, cnt, t, tri, ent)) {  // (a leaf of the wave-uniform program)
                 lds.put(slot, 0, t, mk_meta(ent, k, 0));
                 return 1;
             }
@@ -755,7 +790,7 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, const Pro
             float t;
             uint32_t slot;
             bool ent;
-            if (!mesh_closest<!(FEAT & FEAT_CSG)>(S, S.meshes[r.aux], o, d, mesh_bound, lds, cnt, t, slot, ent)) return false;
+            if (!mesh_closest<!(FEAT & FEAT_CSG), true>(S, S.meshes[r.aux], o, d, mesh_bound, lds, cnt, t, slot, ent)) return false;
             if (!ent) return false;  // a nearer back face hides farther front faces
             t_out = t;
             sub_out = slot;
@@ -835,7 +870,7 @@ __device__ __forceinline__ bool object_step(const DevScene &S, uint32_t k, const
         const ProgRec &leaf = S.prog[k_out];
         float t;
         bool ent;
-        if (leaf.aux >= S.n_meshes || !mesh_closest<false>(S, S.meshes[leaf.aux], o, d, RRT_INF, lds, cnt, t, sub_out, ent)) return false;
+        if (leaf.aux >= S.n_meshes || !mesh_closest<false, false>(S, S.meshes[leaf.aux], o, d, RRT_INF, lds, cnt, t, sub_out, ent)) return false;  // (the lane's own winner)
     }
     return true;
 }

@@ -15,7 +15,10 @@ import bench_extra as bx
 which = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 variants = sys.argv[2:] or ["phong"]
 for variant in variants:
-    scene, cam, ntri = bx.build_mesh_scene(rrt, variant=variant)
+    scene, cam, ntri = bx.build_mesh_scene(rrt, variant="phong" if variant == "sky" else variant)
+    if variant == "sky":  # a camera that sees nothing: the fixed cost of a wave
+        import math
+        cam = rrt.make_camera(3840, 2160, math.radians(40.0), (0.0, 260.0, -420.0), (0.0, -1.0, 0.2))
     scene.pre_render(1)
     W, H = cam.width, cam.height
     rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda"); depth = torch.empty((H, W), dtype=torch.float32, device="cuda"); ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
