@@ -132,6 +132,7 @@ struct DevScene {
     uint32_t n_lights;
     uint32_t has_csg;   // bit 0: some object is a CSG tree; bit 1: some CSG tree has a mesh leaf (the BVH stack then lies behind the hit lists in LDS)
     uint32_t has_bounds;
+    uint32_t no_solids;  // 1: no record is a sphere, a quadric or a cuboid (planes and meshes only): see FEAT_NO_SOLIDS
     uint32_t n_plane_cold, n_meshes, n_materials;  // array sizes, for the device-side index guards
     const PlaneCold *plane_cold;
     const MeshInfo *meshes;

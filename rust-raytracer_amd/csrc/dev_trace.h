@@ -743,7 +743,11 @@ struct CsgState {
 // Scene features a kernel instance is compiled for.  The render kernel is instantiated per feature set (the flags are
 // wave-uniform facts of the scene), so a scene without meshes does not carry the BVH traversal's registers and code, and
 // a scene without CSG does not carry the hit-list machinery.
-enum SceneFeatures : int { FEAT_CSG = 1, FEAT_MESH = 2, FEAT_ALL = 3 };
+// FEAT_NO_SOLIDS: the scene has no sphere, quadric or cuboid record (DevScene::no_solids; planes and meshes only, as the
+// 1 M-triangle frame).  Their cases are then not compiled at all: the compiler hoists the ray-dependent halves of their
+// arithmetic (squares and products of the direction, the cuboid's six dot products) in front of the record loop, where a
+// scene without such records paid them for every ray and every shadow ray (some 200 vector instructions per wave).
+enum SceneFeatures : int { FEAT_CSG = 1, FEAT_MESH = 2, FEAT_ALL = 3, FEAT_NO_SOLIDS = 4 };
 
 // The one entering hit a single-primitive object can produce (list position 0 of a plane, t0 of a
 // sphere / quadric, the cuboid's first_hit, the mesh's closest hit when it faces the ray), with the
@@ -762,6 +766,7 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, const Pro
             return true;
         }
         case OP_SPHERE: {
+            if (FEAT & FEAT_NO_SOLIDS) return false;
             float t0, t1;
             if (!sphere_hits(rec4(r), o, d, t0, t1)) return false;
             if (t0 < 0.0f) return false;
@@ -769,6 +774,7 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, const Pro
             return true;
         }
         case OP_QUADRIC: {
+            if (FEAT & FEAT_NO_SOLIDS) return false;
             float t0, t1;
             if (!quadric_hits(r.p, o, d, t0, t1)) return false;
             if (t0 < 0.0f) return false;
@@ -776,6 +782,7 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, const Pro
             return true;
         }
         case OP_CUBOID: {
+            if (FEAT & FEAT_NO_SOLIDS) return false;
             bool hf, hb;
             float tf, tb;
             uint32_t sf, sb;
@@ -1016,10 +1023,11 @@ __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t
             plane_attr(S, in.aux, sub, o, d, t, h);
             break;
         case OP_CUBOID:
-            if (sub >= 12u || in.aux + 6u > S.n_plane_cold) return;
+            if ((FEAT & FEAT_NO_SOLIDS) || sub >= 12u || in.aux + 6u > S.n_plane_cold) return;
             plane_attr(S, in.aux + (sub >> 1), sub & 1u, o, d, t, h);
             break;
         case OP_SPHERE: {  // sphere_object.rs:55-88
+            if (FEAT & FEAT_NO_SOLIDS) return;
             f3 c = mk3(in.p[0], in.p[1], in.p[2]);
             h.material = in.material;
             h.position = o + d * t;
@@ -1042,6 +1050,7 @@ __device__ __forceinline__ void eval_hit(const DevScene &S, f3 o, f3 d, uint32_t
             break;
         }
         case OP_QUADRIC: {  // quadratic_object.rs:91-118
+            if (FEAT & FEAT_NO_SOLIDS) return;
             const float *q = in.p;  // a b c d e f g h i j
             h.material = in.material;
             f3 p = o + d * t;

@@ -102,6 +102,7 @@ struct TraceArgs {
     uint32_t fuse;        // 1: raytracing mode and level 0 is the whole recursion: k_trace_shade writes the frame itself
     uint32_t tile_order;  // 1: level 0 takes the frame's 8x8 tiles in the XCD-interleaved supertile order (node_pixel); set
                           // where the trace launches are one-wave blocks, i.e. everywhere but raytraced scenes with CSG
+    const uint32_t *tile_table;  // camera frames: place of full tile t of the band, (x / 8) | (y / 8) << 16 (k_tile_table), or null
     float gather_half_width;
     uint32_t *next_count;
     uint32_t *err;
@@ -123,6 +124,7 @@ struct TraceArgs {
 
 void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream);
 void launch_combine(const TraceArgs &a, hipStream_t stream);
+void launch_tile_table(uint32_t *table, uint32_t n_tiles, uint32_t width, uint32_t rows, uint32_t xcd_order, hipStream_t stream);
 void launch_gather_heavy(const TraceArgs &a, hipStream_t stream);  // after launch_trace_shade of the same level (photon mode)
 
 struct BatchTraceArgs {

@@ -38,6 +38,21 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// Sum of a 32-bit value over the 64 lanes of a wave in which EVERY lane is active, as a wave-uniform 64-bit number: the
+// halves of the value are summed apart (no carry can be lost) with four DPP adds each -- quad permutes, then the mirrors of
+// the half row and the row -- and the four rows' sums are read out with v_readlane.  No LDS traffic (a 64-bit __shfl_xor
+// butterfly costs two ds_bpermute per step: the seven statistics of a wave came to some 300 instructions).
+__device__ __forceinline__ uint32_t row_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t v) {
+    return (unsigned long long)row_sum_dpp(v & 0xFFFFu) + ((unsigned long long)row_sum_dpp(v >> 16) << 16);
+}
 __device__ __forceinline__ void flush_counters(const Counters &cnt, unsigned long long gathered, unsigned long long queries,
                                                unsigned long long candidates, unsigned long long *stats, uint32_t *err) {
     unsigned long long n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), s = wave_sum(cnt.shadow);
@@ -116,14 +131,39 @@ __device__ __forceinline__ uint32_t node_pixel(uint32_t g, uint32_t width, uint3
     return full_rows * width + (r - wrem * full_rows);
 }
 
+// node_pixel with its column and band row.  The tiles' places come from a table (k_tile_table: node_pixel itself, once per
+// tile and frame size), because node_pixel's chain of integer divisions cost every wave of a frame some 150 vector
+// instructions, twice (ray and pixel write): 8 % of all the 4K mesh frame issued.  The pixels beside the full tiles keep
+// the arithmetic.
+__device__ __forceinline__ uint32_t frame_pixel(const TraceArgs &A, uint32_t g, uint32_t &x, uint32_t &y) {
+    const uint32_t width = A.cam.width;
+    if (A.tile_table && g < (width >> 3) * 8u * (A.band_rows & ~7u)) {
+        const uint32_t w = A.tile_table[g >> 6], in = g & 63u;
+        x = (w & 0xFFFFu) * 8u + (in & 7u);
+        y = (w >> 16) * 8u + (in >> 3);
+        return y * width + x;
+    }
+    const uint32_t pixel = node_pixel(g, width, A.band_rows, A.tile_order != 0u);
+    y = pixel / width;
+    x = pixel - y * width;
+    return pixel;
+}
+__global__ void k_tile_table(uint32_t *table, uint32_t n_tiles, uint32_t width, uint32_t rows, uint32_t xcd_order) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t pixel = node_pixel(t * 64u, width, rows, xcd_order != 0u);  // the tile's first pixel is its upper left one
+    const uint32_t y = pixel / width, x = pixel - y * width;
+    table[t] = (x >> 3) | ((y >> 3) << 16);
+}
+
 // the ray of node i of the level being processed: generated from the camera (level 0 of a camera render) or read from
 // the level's queue
 __device__ __forceinline__ void level_ray(const TraceArgs &A, uint32_t i, f3 &o, f3 &d) {
     if (A.level == 0 && A.cam.width != 0) {
-        uint32_t pixel = node_pixel(A.pixel_base + i, A.cam.width, A.band_rows, A.tile_order != 0u);
-        uint32_t row = pixel / A.cam.width;  // row of the band (or of the packed rows of an interleaved share)
+        uint32_t x, row;  // row of the band (or of the packed rows of an interleaved share)
+        frame_pixel(A, A.pixel_base + i, x, row);
         if (A.cam.row_stride > 1) row = ((row / A.cam.row_group) * A.cam.row_stride + A.cam.row_first) * A.cam.row_group + row % A.cam.row_group;
-        camera_ray(A.cam, pixel % A.cam.width, A.y0 + row, o, d);
+        camera_ray(A.cam, x, A.y0 + row, o, d);
     } else {
         float4 ro = A.cur.ray_o[i], rd = A.cur.ray_d[i];
         o = mk3(ro.x, ro.y, ro.z);
@@ -202,7 +242,8 @@ __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o,
     // Fused single-level frames (A.fuse: raytracing mode, no material spawns rays, so level 0 is the whole
     // recursion): the pixel is finished here with k_combine's arithmetic and nothing goes through the node arrays.
     constexpr bool fuse = MODE == RRT_MODE_SCENE && FUSE;
-    const uint32_t out_pixel = fuse ? (A.cam.width ? node_pixel(A.pixel_base + i, A.cam.width, A.band_rows, A.tile_order != 0u) : A.pixel_base + i) : 0u;
+    uint32_t out_x, out_y;
+    const uint32_t out_pixel = fuse ? (A.cam.width ? frame_pixel(A, A.pixel_base + i, out_x, out_y) : A.pixel_base + i) : 0u;
     if (tr.object == 0xFFFFFFFFu) {  // scene.rs:85-90 / photon_scene.rs:311-313
         if (fuse) {
             write_pixel(A, out_pixel, mk3(0.0f, 0.0f, 0.0f), 0.0f, 0xFFFFFFFFu);
@@ -314,72 +355,91 @@ __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o,
 // share; the waves' shares are laid end to end through LDS and thread 0 reserves the block's total with a single atomicAdd
 // (one atomic per wave on the one queue counter serialises in the L2: 32 k waves at 1080p).  Every thread of the block
 // must call it (barriers inside).
-template <int BLOCK, bool STATS>
+template <int BLOCK, bool STATS, bool PHOTON>
 __device__ __forceinline__ void finish_block(const TraceArgs &A, uint32_t i, bool write_child, NodeOut &N, const Counters &cnt, const GatherCounts &gc) {
-    __shared__ uint32_t s_wave_a[BLOCK / 64], s_wave_b[BLOCK / 64];
-    __shared__ uint32_t s_block_base;
-    __shared__ unsigned long long s_stat[BLOCK / 64][ST_COUNT];
-    __shared__ uint32_t s_err;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long ma = __ballot(N.want_a), mb = __ballot(N.want_b);
     uint32_t total = __popcll(ma) + __popcll(mb);
-    {
+    // the wave's statistics: the ray counters are 32-bit per lane (DPP sums), the gather's 64-bit (photon mode only)
+    unsigned long long v[ST_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    if (STATS) {
+        v[ST_NODES] = wave_sum_u32(cnt.nodes), v[ST_TRIS] = wave_sum_u32(cnt.tris), v[ST_SHADOW] = wave_sum_u32(cnt.shadow);
+        v[ST_TRUNCATED] = wave_sum_u32(cnt.truncated);
+#ifdef RRT_WALK_STATS
+        if (A.mode == RRT_MODE_SCENE) v[ST_GATHERED] = wave_sum(cnt.ws[0]), v[ST_QUERIES] = wave_sum(cnt.ws[1]), v[ST_CANDIDATES] = wave_sum(cnt.ws[2]);
+#endif
+        if (PHOTON) v[ST_GATHERED] = wave_sum(gc.gathered), v[ST_QUERIES] = wave_sum(gc.queries), v[ST_CANDIDATES] = wave_sum(gc.candidates);
+    }
+    uint32_t block_base = 0, all_a = 0, base_a = 0, base_b = 0, block_total = total;
+    if (BLOCK == 64) {
+        // One-wave blocks: no LDS, no barriers.  Lane k adds statistic k; lane 0 reserves the wave's share of the queue.
+        if (STATS) {
+            const unsigned long long err = __ballot(cnt.overflow != 0);
+            unsigned long long mine = 0;
+#pragma unroll
+            for (int k = 0; k < ST_COUNT; k++) mine = lane == (uint32_t)k ? v[k] : mine;
+            if (lane < ST_COUNT && mine) atomicAdd(&A.stats[(blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE + lane], mine);
+            if (err && cnt.overflow) atomicOr(A.err, cnt.overflow);
+        }
+        if (total) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(A.next_count, total);
+            block_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        }
+        all_a = __popcll(ma);
+        base_a = base_b = block_base;
+    } else {
+        __shared__ uint32_t s_wave_a[BLOCK / 64], s_wave_b[BLOCK / 64];
+        __shared__ uint32_t s_block_base;
+        __shared__ unsigned long long s_stat[BLOCK / 64][ST_COUNT];
+        __shared__ uint32_t s_err;
         if (threadIdx.x == 0) s_err = 0;
         if (lane == 0) {
             s_wave_a[wave] = __popcll(ma);
             s_wave_b[wave] = __popcll(mb);
-        }
-        if (STATS) {
-#ifdef RRT_WALK_STATS
-            unsigned long long v[ST_COUNT] = {cnt.nodes, cnt.tris, cnt.shadow, A.mode == RRT_MODE_SCENE ? cnt.ws[0] : gc.gathered,
-                                              A.mode == RRT_MODE_SCENE ? cnt.ws[1] : gc.queries, A.mode == RRT_MODE_SCENE ? cnt.ws[2] : gc.candidates, cnt.truncated};
-#else
-            unsigned long long v[ST_COUNT] = {cnt.nodes, cnt.tris, cnt.shadow, gc.gathered, gc.queries, gc.candidates, cnt.truncated};
-#endif
-#pragma unroll
-            for (int k = 0; k < ST_COUNT; k++) v[k] = wave_sum(v[k]);
-            if (lane == 0) {
+            if (STATS) {
 #pragma unroll
                 for (int k = 0; k < ST_COUNT; k++) s_stat[wave][k] = v[k];
             }
         }
-    }
-    __syncthreads();
-    if (STATS) {
-        if (cnt.overflow) atomicOr(&s_err, cnt.overflow);
-        if (threadIdx.x < ST_COUNT) {  // thread k owns statistic k
-            unsigned long long sum = 0;
+        __syncthreads();
+        if (STATS) {
+            if (cnt.overflow) atomicOr(&s_err, cnt.overflow);
+            if (threadIdx.x < ST_COUNT) {  // thread k owns statistic k
+                unsigned long long sum = 0;
 #pragma unroll
-            for (int w = 0; w < BLOCK / 64; w++) sum += s_stat[w][threadIdx.x];
-            if (sum) atomicAdd(&A.stats[(blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE + threadIdx.x], sum);
+                for (int w = 0; w < BLOCK / 64; w++) sum += s_stat[w][threadIdx.x];
+                if (sum) atomicAdd(&A.stats[(blockIdx.x % RRT_STAT_COPIES) * RRT_STAT_STRIDE + threadIdx.x], sum);
+            }
         }
-    }
-    if (threadIdx.x == 0) {
-        uint32_t block_total = 0;
+        if (threadIdx.x == 0) {
+            uint32_t bt = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) block_total += s_wave_a[w] + s_wave_b[w];
-        s_block_base = block_total ? atomicAdd(A.next_count, block_total) : 0u;
-    }
-    __syncthreads();
-    if (STATS && threadIdx.x == 0 && s_err) atomicOr(A.err, s_err);
-    int2 child = make_int2(-1, -1);
-    if (total) {
-        // the block's reflection rays first, then its refraction rays: a wave of the next level then holds one kind of
-        // ray from one 8x8-tile neighbourhood, which keeps its rays together at the bound boxes
-        uint32_t all_a = 0, base_a = s_block_base, base_b = s_block_base;
+            for (int w = 0; w < BLOCK / 64; w++) bt += s_wave_a[w] + s_wave_b[w];
+            s_block_base = bt ? atomicAdd(A.next_count, bt) : 0u;
+        }
+        __syncthreads();
+        if (STATS && threadIdx.x == 0 && s_err) atomicOr(A.err, s_err);
+        block_base = s_block_base;
+        block_total = 0;
+        base_a = base_b = block_base;
         for (uint32_t w = 0; w < BLOCK / 64; w++) {
             all_a += s_wave_a[w];
+            block_total += s_wave_a[w] + s_wave_b[w];
             if (w < wave) {
                 base_a += s_wave_a[w];
                 base_b += s_wave_b[w];
             }
         }
+    }
+    int2 child = make_int2(-1, -1);
+    if (total) {
+        // the block's reflection rays first, then its refraction rays: a wave of the next level then holds one kind of
+        // ray from one 8x8-tile neighbourhood, which keeps its rays together at the bound boxes
         base_b += all_a;
         unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
         uint32_t off_a = base_a + __popcll(ma & below), off_b = base_b + __popcll(mb & below);
-        uint32_t block_end = s_block_base;
-        for (uint32_t w = 0; w < BLOCK / 64; w++) block_end += s_wave_a[w] + s_wave_b[w];
-        if (block_end > A.next_limit) {  // prediction too small: the host repeats the frame level by level
+        if (block_base + block_total > A.next_limit) {  // prediction too small: the host repeats the frame level by level
             if (lane == 0) atomicOr(A.err, RRT_ERR_BIT_QUEUE);
             N.want_a = N.want_b = false;
         }
@@ -474,7 +534,7 @@ __global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs 
             }
         }
     }
-    finish_block<BLOCK, true>(A, i, active && !(MODE == RRT_MODE_SCENE && FUSE), N, cnt, gc);
+    finish_block<BLOCK, true, MODE != RRT_MODE_SCENE>(A, i, active && !(MODE == RRT_MODE_SCENE && FUSE), N, cnt, gc);
 }
 
 // Photon mode: the radiance estimates the trace kernel filed (HeavyRec), one query per wave.  Grid-stride over the
@@ -562,7 +622,8 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
     }
     A.cur.result[i] = make_float4(colour.x, colour.y, colour.z, res.w);
     if (A.level == 0) {
-        uint32_t pixel = A.cam.width ? node_pixel(A.pixel_base + i, A.cam.width, A.band_rows, A.tile_order != 0u) : A.pixel_base + i;
+        uint32_t px, py;
+        uint32_t pixel = A.cam.width ? frame_pixel(A, A.pixel_base + i, px, py) : A.pixel_base + i;
         write_pixel(A, pixel, colour, res.w, A.cur.object_id[i]);
     }
 }
@@ -699,7 +760,8 @@ static inline uint32_t blocks_for(uint32_t n) { return (n + RRT_BLOCK - 1) / RRT
 void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream) {
     if (a.count == 0) return;
     // one instance per (mode, scene feature set): see SceneFeatures in dev_trace.h
-    const int feat = (a.S.has_csg ? FEAT_CSG : 0) | (a.S.n_meshes ? FEAT_MESH : 0);
+    int feat = (a.S.has_csg ? FEAT_CSG : 0) | (a.S.n_meshes ? FEAT_MESH : 0);
+    if (feat == FEAT_MESH && a.S.no_solids) feat |= FEAT_NO_SOLIDS;  // planes and meshes only
     // The hit lists / BVH stacks are laid out [element][thread]: the bytes scale with the block.
     // Block size: 64 threads, except raytracing mode on scenes with CSG objects.  A block's registers and LDS return to the
     // pool when its LAST wave is done, and rays differ widely in cost (BVH depth, photon gathers), so one-wave blocks keep
@@ -722,6 +784,7 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
             case 0: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, 0); break;
             case FEAT_CSG: RRT_EITHER(RRT_WIDE, RRT_MODE_SCENE, FEAT_CSG); break;
             case FEAT_MESH: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, FEAT_MESH); break;
+            case FEAT_MESH | FEAT_NO_SOLIDS: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, FEAT_MESH | FEAT_NO_SOLIDS); break;
             default: RRT_EITHER(RRT_WIDE, RRT_MODE_SCENE, FEAT_ALL); break;
         }
     } else if (a.maps[0].div > 1u) {  // fine photon grids (dev_photon.h): the gather adds whole cells
@@ -729,6 +792,7 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
             case 0: RRT_NARROW(MODE_PHOTON_FINE, 0, false); break;
             case FEAT_CSG: RRT_NARROW(MODE_PHOTON_FINE, FEAT_CSG, false); break;
             case FEAT_MESH: RRT_NARROW(MODE_PHOTON_FINE, FEAT_MESH, false); break;
+            case FEAT_MESH | FEAT_NO_SOLIDS: RRT_NARROW(MODE_PHOTON_FINE, FEAT_MESH | FEAT_NO_SOLIDS, false); break;
             default: RRT_NARROW(MODE_PHOTON_FINE, FEAT_ALL, false); break;
         }
     } else {
@@ -736,12 +800,17 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
             case 0: RRT_NARROW(RRT_MODE_PHOTON, 0, false); break;
             case FEAT_CSG: RRT_NARROW(RRT_MODE_PHOTON, FEAT_CSG, false); break;
             case FEAT_MESH: RRT_NARROW(RRT_MODE_PHOTON, FEAT_MESH, false); break;
+            case FEAT_MESH | FEAT_NO_SOLIDS: RRT_NARROW(RRT_MODE_PHOTON, FEAT_MESH | FEAT_NO_SOLIDS, false); break;
             default: RRT_NARROW(RRT_MODE_PHOTON, FEAT_ALL, false); break;
         }
     }
 #undef RRT_EITHER
 #undef RRT_NARROW
 #undef RRT_WIDE
+}
+void launch_tile_table(uint32_t *table, uint32_t n_tiles, uint32_t width, uint32_t rows, uint32_t xcd_order, hipStream_t stream) {
+    if (n_tiles == 0) return;
+    hipLaunchKernelGGL(k_tile_table, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, table, n_tiles, width, rows, xcd_order);
 }
 void launch_gather_heavy(const TraceArgs &a, hipStream_t stream) {
     if (!a.heavy || a.mode != RRT_MODE_PHOTON) return;

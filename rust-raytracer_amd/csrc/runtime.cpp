@@ -673,6 +673,11 @@ int flatten_scene(rrt_scene *s) {
     V.n_lights = (uint32_t)lights.size();
     V.has_csg = (has_csg ? 1u : 0u) | (csg_mesh ? 2u : 0u);
     V.has_bounds = has_bounds ? 1 : 0;
+    V.no_solids = 1;
+    for (const ProgRec &r : F.prog) {
+        const uint32_t op = r.op & 0xFFu;
+        if (op == OP_SPHERE || op == OP_QUADRIC || op == OP_CUBOID) V.no_solids = 0;
+    }
     V.n_plane_cold = (uint32_t)F.plane_cold.size();
     V.n_meshes = (uint32_t)F.meshes.size();
     V.n_materials = (uint32_t)mats.size();
@@ -786,6 +791,23 @@ void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, ui
     A.out_id = id_dev;
 }
 
+// The table of tile places for a camera frame's band (TraceArgs::tile_table): rebuilt on the lane's stream when the
+// frame width, the band height or the tile order changes.
+int set_tile_table(RenderLane &L, TraceArgs &A, hipStream_t st) {
+    A.tile_table = nullptr;
+    const uint32_t n_tiles = (A.cam.width >> 3) * (A.band_rows >> 3);
+    if (n_tiles == 0 || A.cam.width > (0xFFFFu << 3) || A.band_rows > (0xFFFFu << 3)) return RRT_OK;
+    if (L.tt_width != A.cam.width || L.tt_rows != A.band_rows || L.tt_order != A.tile_order + 1u) {
+        int rc;
+        L.tt_width = 0;
+        if ((rc = L.tile_table.ensure(n_tiles))) return rc;
+        launch_tile_table(L.tile_table.p, n_tiles, A.cam.width, A.band_rows, A.tile_order, st);
+        L.tt_width = A.cam.width, L.tt_rows = A.band_rows, L.tt_order = A.tile_order + 1u;
+    }
+    A.tile_table = L.tile_table.p;
+    return RRT_OK;
+}
+
 }  // namespace
 
 // What one render call carries from round to round.
@@ -867,6 +889,7 @@ static int run_round_predicted(FrameRun &R, std::vector<ChunkPlan> &plan, uint32
             launch_load_rays(R.origins_dev + (size_t)plan[j].base * 3, R.directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), st);
         TraceArgs A;
         fill_args(s, A, R.cam, R.y0, R.n_pixels, plan[j].base, R.depth_cap, L, R.rgb_dev, R.depth_dev, R.id_dev);
+        if (R.cam && (rc = set_tile_table(L, A, st))) return rc;
         RRT_HIP(hipEventRecord(L.ev_trace0, st));
         for (uint32_t k = 0; k < n_run; k++) {
             set_level_args(R, A, L, k, caps[k], k ? L.ctr + k : nullptr, caps[k + 1]);  // next_limit 0 behind the last launched level
@@ -931,6 +954,7 @@ static int run_round_by_level(FrameRun &R, std::vector<ChunkPlan> &plan) {
             launch_load_rays(R.origins_dev + (size_t)plan[j].base * 3, R.directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), stream);
         TraceArgs A;
         fill_args(s, A, R.cam, R.y0, R.n_pixels, plan[j].base, R.depth_cap, L, R.rgb_dev, R.depth_dev, R.id_dev);
+        if (R.cam && (rc = set_tile_table(L, A, stream))) return rc;
         uint32_t last = 0;
         for (uint32_t k = 0; k < n_levels; k++) {
             bool spawns = k + 1 < n_levels;

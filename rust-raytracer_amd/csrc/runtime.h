@@ -151,6 +151,8 @@ struct RenderLane {
     hipEvent_t ev_trace0 = nullptr, ev_trace1 = nullptr, ev_done = nullptr;
     DBuf<HeavyRec> heavy;  // photon mode: the queries of the current level filed for k_gather_heavy
     DBuf<uint2> knn;       // photon mode with rrt_params.gather_k: gather_k heap entries per ray of the widest level
+    DBuf<uint32_t> tile_table;  // camera frames: where the band's full 8x8 tiles lie (kernels.hip: k_tile_table), for ...
+    uint32_t tt_width = 0, tt_rows = 0, tt_order = 0;  // ... this frame width, band height and tile order
     // per round of chunks of a frame (a frame larger than the chunk size takes several rounds, each over another part of
     // the image): [0] = chunk size it was measured on, [1 + k] = size of level k
     std::vector<std::vector<uint32_t>> prediction;
