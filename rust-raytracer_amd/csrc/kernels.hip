@@ -462,8 +462,11 @@ __device__ __forceinline__ void finish_block(const TraceArgs &A, uint32_t i, boo
 // BLOCK: threads per block, 64 or 256 (launch_trace_shade says which and why).
 // FUSE: single-level frames (TraceArgs.fuse; raytracing mode only): a compile-time constant so that this instance carries
 // neither the child-ray state nor the node arrays' addresses across the shadow traversal.
+// (Raytraced scenes of planes and meshes only: four waves per SIMD.  The fused instance needs 128 registers as it is; the
+// one with child rays takes 152 and spills 15 of them under the bound, outside its loops: mirror / glass teapots 4.14 / 3.06
+// -> 3.83 / 2.83 ms.)
 template <int MODE, int FEAT, int BLOCK, bool FUSE>
-__global__ __launch_bounds__(BLOCK, RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
+__global__ __launch_bounds__(BLOCK, (MODE == RRT_MODE_SCENE && (FEAT & FEAT_NO_SOLIDS) && RRT_MIN_WAVES < 4) ? 4 : RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
     const DevScene &S = A.S;
     Lds lds = make_lds(A.S, A.lds_slots, BLOCK);
     uint32_t block = blockIdx.x;
