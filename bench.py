@@ -311,7 +311,7 @@ def main():
                 "pre_render_s": t_pre, "ms_bvh_build": st["ms_bvh_build"],
             },
             "roofline": {
-                "kernel": "k_trace_shade<0, 2, 64, true> (traversal + shading; one launch per frame)",
+                "kernel": "k_trace_shade<0, 6, 64, true> (traversal + shading; one launch per frame; the instance for scenes of planes and meshes only)",
                 "bound": "valu_fp32",
                 "achieved": achieved,
                 "peak": PEAK_FP32_TFLOPS,

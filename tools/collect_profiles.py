@@ -37,7 +37,7 @@ def slim(src, dst, kernels):
             if any(k in row[8] for k in kernels):
                 wr.writerow(row)
 
-for tag, name, kernel, cmd in (("c4", "c4_mesh", "k_trace_shade<0, 2,", "python3 bench.py --no-extra --no-cpu-baseline --steps 20 --warmup 3"),
+for tag, name, kernel, cmd in (("c4", "c4_mesh", "k_trace_shade<0, 6,", "python3 bench.py --no-extra --no-cpu-baseline --steps 20 --warmup 3"),
                                ("c3", "c3_photon", "k_trace_shade<1, 3,", "python3 bench_extra.py photon")):
     shutil.copy(os.path.join(G, "%s/%s_stats/%s_kernel_stats.csv" % (TAG, tag, tag)), os.path.join(P, "%s_kernel_stats.csv" % name))
     shutil.copy(os.path.join(G, "%s/%s_stats.json.log" % (TAG, tag)), os.path.join(P, "%s_under_rocprof.json.log" % name))
@@ -74,7 +74,7 @@ for tag, name, kernel, cmd in (("c4", "c4_mesh", "k_trace_shade<0, 2,", "python3
 mem = {}
 for p in ("tcp", "tatd", "sqmem", "tcc", "lat"):
     src = os.path.join(G, "pmc_%s_c4_mem/%s/%s_counter_collection.csv" % (TAG, p, p))
-    s, n = sums(src, "k_trace_shade<0, 2,")
+    s, n = sums(src, "k_trace_shade<0, 6,")
     mem.update(s); mem["launches_" + p] = n
 mem["l1_hit_rate"] = 1.0 - mem["TCP_TCC_READ_REQ_sum"] / mem["TCP_TOTAL_CACHE_ACCESSES_sum"]
 mem["l2_hit_rate"] = mem["TCC_HIT_sum"] / mem["TCC_REQ_sum"]
