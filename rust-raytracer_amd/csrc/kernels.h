@@ -84,14 +84,28 @@ struct HeavyRec {
 #define RRT_HEAVY_THRESHOLD 2048u       // default for rrt_params.gather_heavy_threshold
 #define RRT_HEAVY_COUNTER 32            // lane counters [32 + level] count the records filed by that level
 
+// The queues of the recursion levels >= 1 are STRIPED: RRT_STRIPES dense queues side by side, each with a counter on a
+// cache line of its own.  Block b appends its child rays to stripe b % RRT_STRIPES; the next level's launch deals every
+// stripe's rays to all XCDs (node_slot in kernels.hip).  One counter for the whole level made every appending wave queue up at ONE address (the
+// L2 serialises same-address atomics at about 4.4 ns each: 0.57 ms for the 129 600 one-wave blocks of a 4K level whose
+// every pixel reflects, measured as 1.50 ms against 0.75 ms for the same rays without appends); RRT_STRIPES counters take
+// that many times fewer each, in parallel.
+// Node indices: stripe s of a level holds the nodes [s * stripe_cap, s * stripe_cap + min(counter[s], stripe_cap)).
+#ifndef RRT_STRIPES
+#define RRT_STRIPES 8u
+#endif
+#define RRT_STRIPE_STRIDE 16u  // 32-bit words from one stripe's counter to the next (64 bytes)
+
 struct TraceArgs {
     DevScene S;
     LevelBuffers cur, next;
     DevCamera cam;
     DevPhotonMap maps[2];
-    uint32_t count;       // rays in this level; an upper bound (the launch size) when count_ptr is set
-    const uint32_t *count_ptr;  // device-side count written by the previous level's appends, or null
-    uint32_t next_limit;  // rays the next level's launch will cover: appends beyond it raise RRT_ERR_BIT_QUEUE
+    uint32_t count;       // level 0: rays in this level.  Striped levels: rays per stripe this launch covers
+    const uint32_t *count_ptr;  // striped levels: the level's stripe counters (the previous level's appends wrote them); level 0: null
+    uint32_t striped;     // 0: level 0 (nodes [0, count)); 1: a striped level
+    uint32_t stripe_cap;  // striped levels: nodes per stripe the level's arrays hold
+    uint32_t next_stripe_cap;  // nodes per stripe of the next level: appends beyond it raise RRT_ERR_BIT_QUEUE (0: nothing may be appended)
     uint32_t level;       // recursion depth of these rays
     uint32_t max_depth;   // Scene: global_material.rs:72 (5); PhotonScene: max_vueon_depth
     uint32_t mode;        // rrt_mode
@@ -100,11 +114,11 @@ struct TraceArgs {
     uint32_t band_rows;   // rows of the band being rendered (camera renders)
     uint32_t lds_slots;   // hit-list slots per lane (0 = scene has no CSG)
     uint32_t fuse;        // 1: raytracing mode and level 0 is the whole recursion: k_trace_shade writes the frame itself
-    uint32_t tile_order;  // 1: level 0 takes the frame's 8x8 tiles in the XCD-interleaved supertile order (node_pixel); set
-                          // where the trace launches are one-wave blocks, i.e. everywhere but raytraced scenes with CSG
+    uint32_t tile_order;  // 1: level 0 takes the frame's 8x8 tiles in the XCD-interleaved supertile order (node_pixel), which
+                          // assumes one-wave blocks
     const uint32_t *tile_table;  // camera frames: place of full tile t of the band, (x / 8) | (y / 8) << 16 (k_tile_table), or null
     float gather_half_width;
-    uint32_t *next_count;
+    uint32_t *next_count;  // the next level's stripe counters
     uint32_t *err;
     unsigned long long *stats;
     HeavyRec *heavy;           // null: every lane gathers for itself

@@ -350,6 +350,34 @@ __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o,
     }
 }
 
+// Which node of the level a thread works on (TraceArgs: level 0 is one dense range, the levels behind it are striped).
+struct NodeSlot {
+    uint32_t i;       // node index into the level's arrays
+    bool active;      // the thread has a node
+    bool block_idle;  // no thread of the block has one (launched for the predicted size of the level)
+};
+// (LEVEL0: the caller is an instance that only ever runs level 0, the fused single-level kernels)
+template <int BLOCK, bool LEVEL0 = false>
+__device__ __forceinline__ NodeSlot node_slot(const TraceArgs &A) {
+    NodeSlot n;
+    if (LEVEL0 || !A.striped) {
+        n.i = blockIdx.x * BLOCK + threadIdx.x;
+        n.active = n.i < A.count;
+        n.block_idle = blockIdx.x * BLOCK >= A.count;
+    } else {
+        // Eight consecutive blocks (one per XCD) take eight consecutive blocks' worth of ONE stripe, the next eight of the
+        // next stripe: every stripe is worked on by all XCDs.  (Stripe s on XCD s % 8 alone was measured: a level whose costly
+        // rays come from one patch of the frame then runs on an eighth of the GPU -- level 1 of the photon-mapped scene2
+        // frame, 114 k rays, 0.56 -> 0.67 ms.)
+        const uint32_t s = (blockIdx.x >> 3) % RRT_STRIPES, first = ((blockIdx.x & 7u) + ((blockIdx.x / (8u * RRT_STRIPES)) << 3)) * BLOCK;
+        const uint32_t have = min(A.count_ptr[s * RRT_STRIPE_STRIDE], A.stripe_cap);
+        n.i = s * A.stripe_cap + first + threadIdx.x;
+        n.active = first + threadIdx.x < have;
+        n.block_idle = first >= have;
+    }
+    return n;
+}
+
 // The block-wide tail of a level's kernel: append of the child rays to the next level's queue and (STATS) the statistics,
 // ONE atomic per block each.  Per wave a 64-bit ballot + lane-prefix popcount gives each lane its slot inside the wave's
 // share; the waves' shares are laid end to end through LDS and thread 0 reserves the block's total with a single atomicAdd
@@ -383,7 +411,7 @@ __device__ __forceinline__ void finish_block(const TraceArgs &A, uint32_t i, boo
         }
         if (total) {
             uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(A.next_count, total);
+            if (lane == 0) b = atomicAdd(A.next_count + ((blockIdx.x >> 3) % RRT_STRIPES) * RRT_STRIPE_STRIDE, total);
             block_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
         }
         all_a = __popcll(ma);
@@ -416,7 +444,7 @@ __device__ __forceinline__ void finish_block(const TraceArgs &A, uint32_t i, boo
             uint32_t bt = 0;
 #pragma unroll
             for (int w = 0; w < BLOCK / 64; w++) bt += s_wave_a[w] + s_wave_b[w];
-            s_block_base = bt ? atomicAdd(A.next_count, bt) : 0u;
+            s_block_base = bt ? atomicAdd(A.next_count + ((blockIdx.x >> 3) % RRT_STRIPES) * RRT_STRIPE_STRIDE, bt) : 0u;
         }
         __syncthreads();
         if (STATS && threadIdx.x == 0 && s_err) atomicOr(A.err, s_err);
@@ -439,7 +467,10 @@ __device__ __forceinline__ void finish_block(const TraceArgs &A, uint32_t i, boo
         base_b += all_a;
         unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
         uint32_t off_a = base_a + __popcll(ma & below), off_b = base_b + __popcll(mb & below);
-        if (block_base + block_total > A.next_limit) {  // prediction too small: the host repeats the frame level by level
+        // (positions inside the block's stripe so far; its nodes begin at stripe * next_stripe_cap)
+        const uint32_t stripe_first = ((blockIdx.x >> 3) % RRT_STRIPES) * A.next_stripe_cap;
+        off_a += stripe_first, off_b += stripe_first;
+        if (block_base + block_total > A.next_stripe_cap) {  // prediction too small: the host repeats the frame level by level
             if (lane == 0) atomicOr(A.err, RRT_ERR_BIT_QUEUE);
             N.want_a = N.want_b = false;
         }
@@ -469,11 +500,10 @@ template <int MODE, int FEAT, int BLOCK, bool FUSE>
 __global__ __launch_bounds__(BLOCK, (MODE == RRT_MODE_SCENE && (FEAT & FEAT_NO_SOLIDS) && RRT_MIN_WAVES < 4) ? 4 : RRT_MIN_WAVES) void k_trace_shade(TraceArgs A) {
     const DevScene &S = A.S;
     Lds lds = make_lds(A.S, A.lds_slots, BLOCK);
-    uint32_t block = blockIdx.x;
-    uint32_t i = block * BLOCK + threadIdx.x;
-    uint32_t count = A.count_ptr ? min(*A.count_ptr, A.count) : A.count;
-    bool active = i < count;
-    if (block * BLOCK >= count) return;  // launched for the predicted size of the level
+    const NodeSlot slot = node_slot<BLOCK, MODE == RRT_MODE_SCENE && FUSE>(A);
+    const uint32_t i = slot.i;
+    const bool active = slot.active;
+    if (slot.block_idle) return;  // launched for the predicted size of the level
     Counters cnt = {0, 0, 0, 0};
     GatherCounts gc;
     NodeOut N;
@@ -586,9 +616,9 @@ __global__ __launch_bounds__(64) void k_gather_heavy(TraceArgs A) {
 }
 
 __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
-    uint32_t i = blockIdx.x * RRT_BLOCK + threadIdx.x;
-    uint32_t count = A.count_ptr ? min(*A.count_ptr, A.count) : A.count;
-    if (i >= count) return;
+    const NodeSlot slot = node_slot<RRT_BLOCK>(A);
+    const uint32_t i = slot.i;
+    if (!slot.active) return;
     float4 g = A.cur.glob[i];
     uint32_t flags = __float_as_uint(g.w);
     float4 res = A.cur.result[i];
@@ -759,6 +789,8 @@ void launch_assemble_frame(const uint8_t *parts, uint32_t world, uint32_t rows_m
 }
 
 static inline uint32_t blocks_for(uint32_t n) { return (n + RRT_BLOCK - 1) / RRT_BLOCK; }
+// grid of a level's launch: `blocks` blocks (level 0), or that many per stripe in groups of eight (node_slot)
+static inline uint32_t stripe_blocks(uint32_t blocks, uint32_t striped) { return striped ? (blocks + 7u) / 8u * 8u * RRT_STRIPES : blocks; }
 
 void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream) {
     if (a.count == 0) return;
@@ -766,15 +798,15 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
     int feat = (a.S.has_csg ? FEAT_CSG : 0) | (a.S.n_meshes ? FEAT_MESH : 0);
     if (feat == FEAT_MESH && a.S.no_solids) feat |= FEAT_NO_SOLIDS;  // planes and meshes only
     // The hit lists / BVH stacks are laid out [element][thread]: the bytes scale with the block.
-    // Block size: 64 threads, except raytracing mode on scenes with CSG objects.  A block's registers and LDS return to the
-    // pool when its LAST wave is done, and rays differ widely in cost (BVH depth, photon gathers), so one-wave blocks keep
-    // the SIMDs fuller: 4K mesh frame 1.35 -> 1.21 ms, with mirror / glass teapots +4 / +9 %, photon-mapped scene2 +2 %
-    // (+10 % with three frames in flight), although every wave then pays its own atomic on the queue counter.  The
-    // raytraced CSG scene is the exception (9.6 -> 7.6 Grays/s with one-wave blocks: most of its pixels append two
-    // children), it keeps 256.
-#define RRT_NARROW(M, F, U) hipLaunchKernelGGL((k_trace_shade<M, F, 64, U>), dim3((a.count + 63u) / 64u), dim3(64), lds_bytes / 256 * 64, stream, a)
-#define RRT_WIDE(M, F, U) \
-    hipLaunchKernelGGL((k_trace_shade<M, F, RRT_BLOCK, U>), dim3(blocks_for(a.count)), dim3(RRT_BLOCK), lds_bytes / 256 * RRT_BLOCK, stream, a)
+    // Block size: 64 threads.  A block's registers and LDS return to the pool when its LAST wave is done, and rays differ
+    // widely in cost (BVH depth, photon gathers), so one-wave blocks keep the SIMDs fuller: 4K mesh frame 1.35 -> 1.21 ms,
+    // with mirror / glass teapots +4 / +9 %, photon-mapped scene2 +2 % (+10 % with three frames in flight).  Every wave then
+    // pays an atomic of its own on the queue counter, which used to make the raytraced CSG scene the exception (most of its
+    // pixels append two children: 9.6 -> 7.6 Grays/s with one-wave blocks and ONE counter per level); with the queues
+    // striped over RRT_STRIPES counters it gains as well (kernels 0.450 -> 0.437 ms per frame) and the 256-thread
+    // instances are gone.
+#define RRT_NARROW(M, F, U) \
+    hipLaunchKernelGGL((k_trace_shade<M, F, 64, U>), dim3(stripe_blocks((a.count + 63u) / 64u, a.striped)), dim3(64), lds_bytes / 256 * 64, stream, a)
 #define RRT_EITHER(WHICH, M, F)    \
     do {                           \
         if (a.fuse)                \
@@ -785,10 +817,10 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
     if (a.mode == RRT_MODE_SCENE) {
         switch (feat) {
             case 0: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, 0); break;
-            case FEAT_CSG: RRT_EITHER(RRT_WIDE, RRT_MODE_SCENE, FEAT_CSG); break;
+            case FEAT_CSG: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, FEAT_CSG); break;
             case FEAT_MESH: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, FEAT_MESH); break;
             case FEAT_MESH | FEAT_NO_SOLIDS: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, FEAT_MESH | FEAT_NO_SOLIDS); break;
-            default: RRT_EITHER(RRT_WIDE, RRT_MODE_SCENE, FEAT_ALL); break;
+            default: RRT_EITHER(RRT_NARROW, RRT_MODE_SCENE, FEAT_ALL); break;
         }
     } else if (a.maps[0].div > 1u) {  // fine photon grids (dev_photon.h): the gather adds whole cells
         switch (feat) {
@@ -809,7 +841,6 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
     }
 #undef RRT_EITHER
 #undef RRT_NARROW
-#undef RRT_WIDE
 }
 void launch_tile_table(uint32_t *table, uint32_t n_tiles, uint32_t width, uint32_t rows, uint32_t xcd_order, hipStream_t stream) {
     if (n_tiles == 0) return;
@@ -825,7 +856,7 @@ void launch_gather_heavy(const TraceArgs &a, hipStream_t stream) {
 
 void launch_combine(const TraceArgs &a, hipStream_t stream) {
     if (a.count == 0) return;
-    hipLaunchKernelGGL(k_combine, dim3(blocks_for(a.count)), dim3(RRT_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(k_combine, dim3(stripe_blocks(blocks_for(a.count), a.striped)), dim3(RRT_BLOCK), 0, stream, a);
 }
 void launch_batch_trace(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream) {
     if (a.n == 0) return;

@@ -19,6 +19,7 @@ rrt_scene::~rrt_scene() {
         if (L->ev_trace1) (void)hipEventDestroy(L->ev_trace1);
         if (L->ev_done) (void)hipEventDestroy(L->ev_done);
         if (L->host_pinned && L->owns_pinned) (void)hipHostFree(L->host_pinned);
+        if (L->stripe_pinned && L->owns_stripe_pinned) (void)hipHostFree(L->stripe_pinned);
     }
 }
 
@@ -698,13 +699,17 @@ int flatten_scene(rrt_scene *s) {
     return ensure_workspace(s);
 }
 
+#define RRT_MAX_LEVELS 64u  // levels a lane's stripe counters are laid out for (render_rays_impl refuses more than 58)
+constexpr size_t kStripeWordsPerLevel = (size_t)RRT_STRIPES * RRT_STRIPE_STRIDE;       // 32-bit words
+constexpr size_t kStripeWordsAll = (size_t)RRT_MAX_LEVELS * kStripeWordsPerLevel;
+
 int ensure_workspace(rrt_scene *s) {
     int rc;
     if ((rc = s->counters.ensure(64))) return rc;
-    // lane 0's 64 queue counters live right behind the statistics (device and pinned host copies alike), so that one
-    // memset clears both at the start of a frame and one copy brings both back at its end
-    if ((rc = s->stats_dev.ensure(RRT_STAT_WORDS + 32))) return rc;
-    if (!s->host_pinned) RRT_HIP(hipHostMalloc((void **)&s->host_pinned, (RRT_STAT_WORDS + 32) * sizeof(unsigned long long)));
+    // lane 0's 64 counters and the stripe counters of its level queues live right behind the statistics (device and pinned
+    // host copies alike), so that one memset clears all of them at the start of a frame and one copy brings them back at its end
+    if ((rc = s->stats_dev.ensure(RRT_STAT_WORDS + 32 + kStripeWordsAll / 2))) return rc;
+    if (!s->host_pinned) RRT_HIP(hipHostMalloc((void **)&s->host_pinned, (RRT_STAT_WORDS + 32 + kStripeWordsAll / 2) * sizeof(unsigned long long)));
     while (s->events.size() < 4) {
         hipEvent_t e;
         RRT_HIP(hipEventCreate(&e));
@@ -746,7 +751,13 @@ int ensure_lanes(rrt_scene *s, uint32_t n) {
         if (s->lanes.size() == 1) {  // lane 0 borrows the tail of the statistics buffers (see ensure_workspace)
             L.ctr = reinterpret_cast<uint32_t *>(s->stats_dev.p + RRT_STAT_WORDS);
             L.host_pinned = s->host_pinned + 2 * RRT_STAT_WORDS;
+            L.stripe = reinterpret_cast<uint32_t *>(s->stats_dev.p + RRT_STAT_WORDS + 32);
+            L.stripe_pinned = s->host_pinned + 2 * (RRT_STAT_WORDS + 32);
         } else {
+            if ((rc = L.stripe_own.ensure(kStripeWordsAll))) return rc;
+            L.stripe = L.stripe_own.p;
+            RRT_HIP(hipHostMalloc((void **)&L.stripe_pinned, kStripeWordsAll * sizeof(uint32_t)));
+            L.owns_stripe_pinned = true;
             if ((rc = L.counters.ensure(64))) return rc;
             L.ctr = L.counters.p;
             RRT_HIP(hipHostMalloc((void **)&L.host_pinned, 64 * sizeof(uint32_t)));
@@ -763,6 +774,7 @@ int ensure_lanes(rrt_scene *s, uint32_t n) {
 struct ChunkPlan {
     uint32_t base, n;
     std::vector<uint32_t> counts;  // rays per level, filled in when known
+    std::vector<uint32_t> most;    // rays in the fullest stripe of each level >= 1
 };
 
 void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, uint32_t n_pixels, uint32_t base, uint32_t depth_cap,
@@ -780,7 +792,7 @@ void fill_args(rrt_scene *s, TraceArgs &A, const DevCamera *cam, uint32_t y0, ui
     A.band_rows = cam && cam->width ? n_pixels / cam->width : 0;
     A.lds_slots = D.lds_slots;
     A.fuse = (s->mode == RRT_MODE_SCENE && !D.reflective) ? 1u : 0u;  // single-level frames need no combine pass
-    A.tile_order = (s->mode == RRT_MODE_SCENE && D.view.has_csg) ? 0u : 1u;  // as launch_trace_shade picks the block size
+    A.tile_order = 1u;  // (every trace launch is made of one-wave blocks: launch_trace_shade)
     A.gather_half_width = s->params.gather_half_width;
     A.err = L.ctr + 63;
     A.stats = s->stats_dev.p;
@@ -829,20 +841,39 @@ struct FrameRun {
     uint32_t err = 0;
 };
 
-static void set_level_args(FrameRun &R, TraceArgs &A, RenderLane &L, uint32_t k, uint32_t count, const uint32_t *count_ptr, uint32_t next_limit) {
+// Level k of a chunk.  `cover`: level 0: its rays; a striped level: rays per stripe the launch covers.  scap / scap_next:
+// nodes per stripe the arrays of this level and of the next one hold (scap_next 0: nothing may be appended).
+static void set_level_args(FrameRun &R, TraceArgs &A, RenderLane &L, uint32_t k, uint32_t cover, uint32_t scap, uint32_t scap_next) {
     A.cur = L.levels[k].view();
     A.next = L.levels[k + 1].view();
-    A.count = count;
-    A.count_ptr = count_ptr;
-    A.next_limit = next_limit;
+    A.count = cover;
+    A.striped = k ? 1u : 0u;
+    A.stripe_cap = scap;
+    A.count_ptr = k ? L.stripe + k * kStripeWordsPerLevel : nullptr;
+    A.next_stripe_cap = scap_next;
     A.level = k;
-    A.next_count = L.ctr + (k + 1);
+    A.next_count = L.stripe + (k + 1) * kStripeWordsPerLevel;
     A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
     A.heavy = L.heavy.p;
-    A.heavy_capacity = count;
+    const uint32_t nodes = k ? RRT_STRIPES * scap : cover;  // node indices of the level run below this
+    A.heavy_capacity = nodes;
     A.knn_k = R.knn_k;
     A.knn_ws = L.knn.p;
-    A.knn_stride = count;
+    A.knn_stride = nodes;
+}
+// most child rays one stripe of level 1 can receive from a level 0 of n rays (blocks of 64 or 256 rays, dealt round-robin)
+static uint32_t level1_stripe_bound(uint32_t n) { return 2u * (n / RRT_STRIPES + 512u); }
+// ... and from a striped level none of whose stripes holds more than `most` rays: the blocks that append to one stripe
+// (those with the same index modulo 8) work on every eighth block of every stripe (node_slot), two children per ray
+static uint32_t stripe_children_bound(uint32_t most) { return 2u * (most + 8u * 256u); }
+// sum and maximum over the stripes of one level's counters (host copy)
+static void stripe_counts(const uint32_t *level_words, uint32_t &total, uint32_t &most) {
+    total = most = 0;
+    for (uint32_t q = 0; q < RRT_STRIPES; q++) {
+        const uint32_t c = level_words[q * RRT_STRIPE_STRIDE];
+        total += c;
+        most = std::max(most, c);
+    }
 }
 
 // One round of chunks launched for the level sizes of the previous frame: no readback between launches, one sync at the
@@ -854,6 +885,7 @@ static int run_round_predicted(FrameRun &R, std::vector<ChunkPlan> &plan, uint32
     const uint32_t n_levels = R.n_levels;
     int rc;
     overflow = false;
+    uint32_t copy_levels = 0;  // levels whose stripe counters ride on the frame's one copy
     if (plan.size() > 1) {  // fork: the other lanes start after what the caller's stream holds so far
         RRT_HIP(hipEventRecord(s->events[2], stream));
         for (size_t j = 1; j < plan.size(); j++) RRT_HIP(hipStreamWaitEvent(s->lanes[j]->stream, s->events[2], 0));
@@ -861,12 +893,13 @@ static int run_round_predicted(FrameRun &R, std::vector<ChunkPlan> &plan, uint32
     for (size_t j = 0; j < plan.size(); j++) {
         RenderLane &L = *s->lanes[j];
         hipStream_t st = j == 0 ? stream : L.stream;
-        const std::vector<uint32_t> &pred = L.prediction[round];
-        std::vector<uint32_t> caps(n_levels + 1, 0);
-        caps[0] = plan[j].n;
+        const std::vector<uint32_t> &pred = L.prediction[round];  // [0] chunk size, [1 + k] rays of level k, [2 + n_levels + k] its fullest stripe
+        // scap[k]: nodes per stripe the arrays of level k >= 1 hold, and the launch covers: what the fullest stripe held in
+        // the previous frame + an eighth + 256, never more than the level before could fill
+        std::vector<uint32_t> scap(n_levels + 2, 0);
         // Levels the previous frame left empty are not launched at all (a photon-mapped frame of scene2 has rays on 2
-        // of its 13 levels): the last launched level gets next_limit 0, so a ray that does want to go deeper raises
-        // RRT_ERR_BIT_QUEUE and the frame is repeated level by level, like any other outgrown prediction.
+        // of its 13 levels): the last launched level may append nothing (next_stripe_cap 0), so a ray that does want to go
+        // deeper raises RRT_ERR_BIT_QUEUE and the frame is repeated level by level, like any other outgrown prediction.
         uint32_t n_run = n_levels;
         for (uint32_t k = 1; k < n_levels; k++)
             if (pred[1 + k] == 0) {
@@ -874,16 +907,21 @@ static int run_round_predicted(FrameRun &R, std::vector<ChunkPlan> &plan, uint32
                 break;
             }
         if ((rc = L.levels[0].ensure(plan[j].n, R.n_lights, R.cam == nullptr))) return rc;
+        uint32_t widest = plan[j].n;
         for (uint32_t k = 1; k < n_run; k++) {
-            uint64_t want = (uint64_t)pred[1 + k] + pred[1 + k] / 8 + 4096;
-            caps[k] = (uint32_t)std::min<uint64_t>(want, 2ull * caps[k - 1]);
-            if ((rc = L.levels[k].ensure(caps[k], R.n_lights, true))) return rc;
+            const uint32_t most = pred[2 + n_levels + k];
+            const uint64_t want = (uint64_t)most + most / 8 + 256;
+            scap[k] = (uint32_t)std::min<uint64_t>(want, k == 1 ? level1_stripe_bound(plan[j].n) : stripe_children_bound(scap[k - 1]));
+            if ((rc = L.levels[k].ensure(RRT_STRIPES * scap[k], R.n_lights, true))) return rc;
+            widest = std::max(widest, RRT_STRIPES * scap[k]);
         }
         if ((rc = L.levels[n_run].ensure(1, R.n_lights, true))) return rc;
-        const uint32_t widest = *std::max_element(caps.begin(), caps.end());
         if (R.heavy_queue && (rc = L.heavy.ensure(widest))) return rc;
         if (R.knn_k && (rc = L.knn.ensure((size_t)R.knn_k * widest))) return rc;
-        if (!(j == 0 && R.lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), st));
+        if (!(j == 0 && R.lane0_clean)) {  // (the frame's first memset has cleared lane 0's counters with the statistics)
+            RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), st));
+            if (n_levels > 1) RRT_HIP(hipMemsetAsync(L.stripe, 0, (n_run + 1) * kStripeWordsPerLevel * sizeof(uint32_t), st));
+        }
         if (j == 0) R.lane0_clean = false;
         if (!R.cam)
             launch_load_rays(R.origins_dev + (size_t)plan[j].base * 3, R.directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), st);
@@ -892,17 +930,22 @@ static int run_round_predicted(FrameRun &R, std::vector<ChunkPlan> &plan, uint32
         if (R.cam && (rc = set_tile_table(L, A, st))) return rc;
         RRT_HIP(hipEventRecord(L.ev_trace0, st));
         for (uint32_t k = 0; k < n_run; k++) {
-            set_level_args(R, A, L, k, caps[k], k ? L.ctr + k : nullptr, caps[k + 1]);  // next_limit 0 behind the last launched level
+            set_level_args(R, A, L, k, k ? scap[k] : plan[j].n, scap[k], k + 1 < n_run ? scap[k + 1] : 0u);
             launch_trace_shade(A, D.lds_bytes, st);
             launch_gather_heavy(A, st);
         }
         RRT_HIP(hipEventRecord(L.ev_trace1, st));
         for (int k = (int)n_run - 1; k >= 0 && !A.fuse; k--) {
-            set_level_args(R, A, L, (uint32_t)k, caps[k], k ? L.ctr + k : nullptr, 0);
+            set_level_args(R, A, L, (uint32_t)k, k ? scap[k] : plan[j].n, scap[k], k + 1 < (int)n_run ? scap[k + 1] : 0u);
             launch_combine(A, st);
         }
         const bool one_copy = plan.size() == 1 && last_round;  // statistics + counters in one go below
-        if (!one_copy) RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (!one_copy) {
+            RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            if (n_run > 1)
+                RRT_HIP(hipMemcpyAsync(L.stripe_pinned, L.stripe, n_run * kStripeWordsPerLevel * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        }
+        copy_levels = std::max(copy_levels, n_run > 1 ? n_run : 0u);
         if (j > 0) {  // join
             RRT_HIP(hipEventRecord(L.ev_done, st));
             RRT_HIP(hipStreamWaitEvent(stream, L.ev_done, 0));
@@ -911,7 +954,9 @@ static int run_round_predicted(FrameRun &R, std::vector<ChunkPlan> &plan, uint32
     if (last_round) {  // the frame's end event and the stats ride on the same sync
         unsigned long long *st_all = reinterpret_cast<unsigned long long *>(s->host_pinned);
         RRT_HIP(hipEventRecord(s->events[1], stream));
-        RRT_HIP(hipMemcpyAsync(st_all, s->stats_dev.p, (RRT_STAT_WORDS + (plan.size() == 1 ? 32 : 0)) * sizeof(unsigned long long),
+        RRT_HIP(hipMemcpyAsync(st_all, s->stats_dev.p,
+                               (RRT_STAT_WORDS + (plan.size() == 1 ? 32 : 0)) * sizeof(unsigned long long) +
+                                   (plan.size() == 1 ? copy_levels * kStripeWordsPerLevel * sizeof(uint32_t) : 0),
                                hipMemcpyDeviceToHost, stream));
         R.tail_done = true;
     }
@@ -922,9 +967,15 @@ static int run_round_predicted(FrameRun &R, std::vector<ChunkPlan> &plan, uint32
     for (size_t j = 0; j < plan.size(); j++) {
         RenderLane &L = *s->lanes[j];
         R.err |= L.host_pinned[63];
-        for (uint32_t k = 1; k < n_levels; k++) {
-            plan[j].counts[k] = L.host_pinned[k];
-            R.secondary += L.host_pinned[k];
+        uint32_t n_run = n_levels;  // (as above: the levels that were launched)
+        for (uint32_t k = 1; k < n_levels; k++)
+            if (L.prediction[round][1 + k] == 0) {
+                n_run = k;
+                break;
+            }
+        for (uint32_t k = 1; k < n_run; k++) {
+            stripe_counts(L.stripe_pinned + k * kStripeWordsPerLevel, plan[j].counts[k], plan[j].most[k]);
+            R.secondary += plan[j].counts[k];
         }
         float t0 = 0.0f, t1 = 0.0f;
         RRT_HIP(hipEventElapsedTime(&t0, s->events[0], L.ev_trace0));
@@ -946,9 +997,12 @@ static int run_round_by_level(FrameRun &R, std::vector<ChunkPlan> &plan) {
     int rc;
     for (size_t j = 0; j < plan.size(); j++) {
         RenderLane &L = *s->lanes[j];
-        std::vector<uint32_t> &counts = plan[j].counts;
+        std::vector<uint32_t> &counts = plan[j].counts, &most = plan[j].most;
         if ((rc = L.levels[0].ensure(plan[j].n, R.n_lights, R.cam == nullptr))) return rc;
-        if (!(j == 0 && R.lane0_clean)) RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), stream));
+        if (!(j == 0 && R.lane0_clean)) {
+            RRT_HIP(hipMemsetAsync(L.ctr, 0, 64 * sizeof(uint32_t), stream));
+            if (n_levels > 1) RRT_HIP(hipMemsetAsync(L.stripe, 0, (n_levels + 1) * kStripeWordsPerLevel * sizeof(uint32_t), stream));
+        }
         if (j == 0) R.lane0_clean = false;
         if (!R.cam)
             launch_load_rays(R.origins_dev + (size_t)plan[j].base * 3, R.directions_dev + (size_t)plan[j].base * 3, plan[j].n, L.levels[0].view(), stream);
@@ -956,13 +1010,16 @@ static int run_round_by_level(FrameRun &R, std::vector<ChunkPlan> &plan) {
         fill_args(s, A, R.cam, R.y0, R.n_pixels, plan[j].base, R.depth_cap, L, R.rgb_dev, R.depth_dev, R.id_dev);
         if (R.cam && (rc = set_tile_table(L, A, stream))) return rc;
         uint32_t last = 0;
+        std::vector<uint32_t> scap(n_levels + 2, 0);  // nodes per stripe of each level's arrays
         for (uint32_t k = 0; k < n_levels; k++) {
             bool spawns = k + 1 < n_levels;
-            if (spawns && (rc = L.levels[k + 1].ensure(2 * counts[k], R.n_lights, true))) return rc;
+            scap[k + 1] = spawns ? (k == 0 ? level1_stripe_bound(plan[j].n) : stripe_children_bound(most[k])) : 0u;
+            if (spawns && (rc = L.levels[k + 1].ensure(RRT_STRIPES * scap[k + 1], R.n_lights, true))) return rc;
             // the stream is idle here (synchronised after the previous level): growing the per-level buffers is safe
-            if (R.heavy_queue && (rc = L.heavy.ensure(counts[k]))) return rc;
-            if (R.knn_k && (rc = L.knn.ensure((size_t)R.knn_k * counts[k]))) return rc;
-            set_level_args(R, A, L, k, counts[k], nullptr, spawns ? 2 * counts[k] : 0);
+            const uint32_t nodes = k ? RRT_STRIPES * scap[k] : counts[0];
+            if (R.heavy_queue && (rc = L.heavy.ensure(nodes))) return rc;
+            if (R.knn_k && (rc = L.knn.ensure((size_t)R.knn_k * nodes))) return rc;
+            set_level_args(R, A, L, k, k ? most[k] : counts[0], scap[k], scap[k + 1]);
             RRT_HIP(hipEventRecord(L.ev_trace0, stream));
             launch_trace_shade(A, D.lds_bytes, stream);
             launch_gather_heavy(A, stream);
@@ -970,9 +1027,10 @@ static int run_round_by_level(FrameRun &R, std::vector<ChunkPlan> &plan) {
             last = k;
             uint32_t next_n = 0;
             if (spawns) {
-                RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr + (k + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                RRT_HIP(hipMemcpyAsync(L.stripe_pinned, L.stripe + (k + 1) * kStripeWordsPerLevel, kStripeWordsPerLevel * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, stream));
                 RRT_HIP(hipStreamSynchronize(stream));
-                next_n = L.host_pinned[0];
+                stripe_counts(L.stripe_pinned, next_n, most[k + 1]);
             } else {
                 RRT_HIP(hipStreamSynchronize(stream));
             }
@@ -997,7 +1055,7 @@ static int run_round_by_level(FrameRun &R, std::vector<ChunkPlan> &plan) {
             if (next_n == 0) break;
         }
         for (int k = (int)last; k >= 0 && !A.fuse; k--) {
-            set_level_args(R, A, L, (uint32_t)k, counts[k], nullptr, 0);
+            set_level_args(R, A, L, (uint32_t)k, k ? most[k] : counts[0], scap[k], scap[k + 1]);
             launch_combine(A, stream);
         }
         RRT_HIP(hipMemcpyAsync(L.host_pinned, L.ctr + 63, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1048,7 +1106,9 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
         if (!R.knn_k) s->lanes[j]->knn.release();
     }
 
-    RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0, (RRT_STAT_WORDS + 32) * sizeof(unsigned long long), stream));  // + lane 0's counters
+    RRT_HIP(hipMemsetAsync(s->stats_dev.p, 0,
+                           (RRT_STAT_WORDS + 32) * sizeof(unsigned long long) + (n_levels > 1 ? (n_levels + 1) * kStripeWordsPerLevel * sizeof(uint32_t) : 0),
+                           stream));  // + lane 0's counters and the stripe counters of its levels
     RRT_HIP(hipEventRecord(s->events[0], stream));
     unsigned long long *st_all = reinterpret_cast<unsigned long long *>(s->host_pinned);  // RRT_STAT_WORDS slots
 
@@ -1062,6 +1122,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
             c.base = round_base;
             c.n = std::min(chunk, n_pixels - round_base);
             c.counts.assign(n_levels + 1, 0);
+            c.most.assign(n_levels + 1, 0);
             c.counts[0] = c.n;
             plan.push_back(c);
             round_base += c.n;
@@ -1070,7 +1131,7 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
         for (size_t j = 0; j < plan.size(); j++) {
             const auto &all = s->lanes[j]->prediction;
             const std::vector<uint32_t> &pred = round < all.size() ? all[round] : no_prediction;
-            if (!(pred.size() == n_levels + 2 && pred[0] == plan[j].n)) predicted = false;
+            if (!(pred.size() == 2 * n_levels + 3 && pred[0] == plan[j].n)) predicted = false;
         }
         if (predicted) {
             bool overflow = false;
@@ -1087,9 +1148,9 @@ static int render_rays_impl(rrt_scene *s, const DevCamera *cam, uint32_t y0, uin
         for (size_t j = 0; j < plan.size(); j++) {
             if (s->lanes[j]->prediction.size() <= round) s->lanes[j]->prediction.resize(round + 1);
             std::vector<uint32_t> &pred = s->lanes[j]->prediction[round];
-            pred.assign(n_levels + 2, 0);
+            pred.assign(2 * n_levels + 3, 0);  // [0] chunk size, [1 + k] rays of level k, [2 + n_levels + k] rays in its fullest stripe
             pred[0] = plan[j].n;
-            for (uint32_t k = 0; k <= n_levels; k++) pred[1 + k] = plan[j].counts[k];
+            for (uint32_t k = 0; k <= n_levels; k++) pred[1 + k] = plan[j].counts[k], pred[2 + n_levels + k] = plan[j].most[k];
         }
     }
     if (!R.tail_done) {

@@ -144,7 +144,14 @@ namespace rrt {
 struct RenderLane {
     std::vector<LevelStorage> levels;
     DBuf<uint32_t> counters;  // lanes > 0 own their counters; lane 0 borrows the tail of the statistics buffer
-    uint32_t *ctr = nullptr;  // [k] = rays queued for level k, [63] = error bits
+    uint32_t *ctr = nullptr;  // [32 + k] = heavy radiance estimates filed by level k, [63] = error bits
+    // the stripe counters of the level queues (kernels.h: RRT_STRIPES): counter s of level k at [(k * RRT_STRIPES + s) * RRT_STRIPE_STRIDE]
+    // (lane 0's lie behind its other counters in the statistics buffers, device and pinned host copies alike: one memset,
+    // one copy per frame; the other lanes own theirs)
+    DBuf<uint32_t> stripe_own;
+    uint32_t *stripe = nullptr;
+    uint32_t *stripe_pinned = nullptr;
+    bool owns_stripe_pinned = false;
     uint32_t *host_pinned = nullptr;
     bool owns_pinned = false;
     hipStream_t stream = nullptr;
