@@ -175,13 +175,15 @@ __device__ __forceinline__ void level_ray(const TraceArgs &A, uint32_t i, f3 &o,
 
 // level-0 outputs: the frame (any pointer may be null)
 __device__ __forceinline__ void write_pixel(const TraceArgs &A, uint32_t pixel, f3 colour, float depth, uint32_t object) {
+    // (non-temporal stores: the frame is written once and never read by the kernels, so it need not push BVH nodes out of
+    //  the L2: 0.753 -> 0.748 ms on the 4K mesh frame)
     if (A.out_rgb) {
-        A.out_rgb[(size_t)pixel * 3 + 0] = colour.x;
-        A.out_rgb[(size_t)pixel * 3 + 1] = colour.y;
-        A.out_rgb[(size_t)pixel * 3 + 2] = colour.z;
+        __builtin_nontemporal_store(colour.x, &A.out_rgb[(size_t)pixel * 3 + 0]);
+        __builtin_nontemporal_store(colour.y, &A.out_rgb[(size_t)pixel * 3 + 1]);
+        __builtin_nontemporal_store(colour.z, &A.out_rgb[(size_t)pixel * 3 + 2]);
     }
-    if (A.out_depth) A.out_depth[pixel] = depth;
-    if (A.out_id) A.out_id[pixel] = object;
+    if (A.out_depth) __builtin_nontemporal_store(depth, &A.out_depth[pixel]);
+    if (A.out_id) __builtin_nontemporal_store(object, &A.out_id[pixel]);
 }
 
 // Material part of Scene::raytrace's colour for one node, in the reference's operation order: the fold of the parts'
