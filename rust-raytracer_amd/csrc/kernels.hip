@@ -158,6 +158,23 @@ __global__ void k_tile_table(uint32_t *table, uint32_t n_tiles, uint32_t width, 
     table[t] = (x >> 3) | ((y >> 3) << 16);
 }
 
+// A node's record is written by k_trace_shade and read once, a whole frame later, by k_combine: non-temporal stores, so
+// that it does not push BVH nodes and scene records out of the L2 on its way to memory.
+// (Mirror / glass teapots at 4K: kernels 3.33 / 2.83 -> 3.25 / 2.75 ms.)
+typedef float rrt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void node_store(float4 *p, float4 v) {
+    rrt_v4f w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<rrt_v4f *>(p));
+}
+// ... and read that way by k_combine (frames 1 % shorter)
+__device__ __forceinline__ float4 node_load(const float4 *p) {
+    rrt_v4f w = __builtin_nontemporal_load(reinterpret_cast<const rrt_v4f *>(p));
+    return make_float4(w.x, w.y, w.z, w.w);
+}
+
+// (The ray queues are another matter: the next level's launch finds much of them in the L2.  Non-temporal ray stores and
+//  loads were measured -- mirror / glass teapots 1 % slower, the C2 frame 4 % -- and so were non-temporal triangle loads,
+//  which cost the 4K mesh frame 11 %: neighbouring rays test the same triangles.)
 // the ray of node i of the level being processed: generated from the camera (level 0 of a camera render) or read from
 // the level's queue
 __device__ __forceinline__ void level_ray(const TraceArgs &A, uint32_t i, f3 &o, f3 &d) {
@@ -171,20 +188,6 @@ __device__ __forceinline__ void level_ray(const TraceArgs &A, uint32_t i, f3 &o,
         o = mk3(ro.x, ro.y, ro.z);
         d = mk3(rd.x, rd.y, rd.z);
     }
-}
-
-// A node's record is written by k_trace_shade and read once, a whole frame later, by k_combine: non-temporal stores, so
-// that it does not push BVH nodes and scene records out of the L2 on its way to memory.
-// (Mirror / glass teapots at 4K: kernels 3.33 / 2.83 -> 3.25 / 2.75 ms.)
-typedef float rrt_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void node_store(float4 *p, float4 v) {
-    rrt_v4f w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, reinterpret_cast<rrt_v4f *>(p));
-}
-// ... and read that way by k_combine (frames 1 % shorter)
-__device__ __forceinline__ float4 node_load(const float4 *p) {
-    rrt_v4f w = __builtin_nontemporal_load(reinterpret_cast<const rrt_v4f *>(p));
-    return make_float4(w.x, w.y, w.z, w.w);
 }
 
 // level-0 outputs: the frame (any pointer may be null)
