@@ -855,6 +855,17 @@ static void set_level_args(FrameRun &R, TraceArgs &A, RenderLane &L, uint32_t k,
     A.next_count = L.stripe + (k + 1) * kStripeWordsPerLevel;
     A.heavy_count = L.ctr + RRT_HEAVY_COUNTER + k;
     A.heavy = L.heavy.p;
+    {
+        // Photon mode, threshold derived from the maps (rrt_params.gather_heavy_threshold 0): the levels behind the first hold
+        // few, incoherent rays -- their launch does not fill the GPU and lasts as long as its slowest LANE, which gathers up
+        // to `threshold` candidate records four loads at a time.  They hand their queries over to the wave-per-query kernel
+        // at an eighth of the threshold (not below 256): level 1 of the photon-mapped scene2 frame (114 k rays) 0.55 -> 0.32 ms.
+        // A function of the ray's level and the maps only, so frames stay independent of bands and chunks.
+        rrt_scene *s = R.s;
+        const uint32_t base = s->params.gather_heavy_threshold ? s->params.gather_heavy_threshold : s->heavy_auto;
+        const uint32_t deep = std::max(256u, base / 8u);
+        A.heavy_threshold = (k && s->params.gather_heavy_threshold == 0) ? std::min(base, deep) : base;
+    }
     const uint32_t nodes = k ? RRT_STRIPES * scap : cover;  // node indices of the level run below this
     A.heavy_capacity = nodes;
     A.knn_k = R.knn_k;
