@@ -236,11 +236,18 @@ __device__ __forceinline__ void cuboid_hits(const ProgRec &C, f3 o, f3 d, bool &
 // Triangle::intersect (triangle_object.rs:129-160) on the finite plane hit only (the infinite ones
 // can never be selected: see DESIGN.md "mesh semantics").  Returns true when the hit point passes
 // the same-side test; `entering` is the plane hit's facing.
+template <bool EAGER = false>
 __device__ __forceinline__ bool tri_test(const TriHot &T, f3 o, f3 d, float &t, bool &entering) {
     f3 n = mk3(T.a_nx.w, T.b_ny.w, T.c_nz.w);
     float U = dot3(n, o) + T.d_pad.x;
     float V = dot3(n, d);
-    if (V == 0.0f) return false;
+    // EAGER: no early exit for a ray parallel to the plane.  With the exit the compiler loads the plane, tests V and only then
+    // asks for the corners, so every triangle waits for the memory twice; without it the record comes in one round trip
+    // (the quotient of a parallel ray is computed and thrown away).  Mirror / glass teapots at 4K: kernels 3.26 / 2.72 ->
+    // 3.09 / 2.61 ms.  The fused single-level instance keeps the exit: it sits at its 128-register bound and the wider
+    // live range costs it more scalar spills than the round trip (0.741 -> 0.743 ms).
+    const bool crosses = V != 0.0f;
+    if (!EAGER && !crosses) return false;
     t = U / -V;
     entering = !(V > 0.0f);
     f3 a = mk3(T.a_nx.x, T.a_nx.y, T.a_nx.z), b = mk3(T.b_ny.x, T.b_ny.y, T.b_ny.z), c = mk3(T.c_nz.x, T.c_nz.y, T.c_nz.z);
@@ -248,6 +255,7 @@ __device__ __forceinline__ bool tri_test(const TriHot &T, f3 o, f3 d, float &t, 
     f3 ai = p - a, bi = p - b, ci = p - c;
     f3 ab = b - a, bc = c - b, ca = a - c;  // Triangle::new, triangle_object.rs:51-53
     f3 ab_n = cross3(ai, ab), bc_n = cross3(bi, bc), ca_n = cross3(ci, ca);
+    if (EAGER) return ((int)crosses & (int)(dot3(ab_n, bc_n) > 0.0f) & (int)(dot3(bc_n, ca_n) > 0.0f)) != 0;
     return dot3(ab_n, bc_n) > 0.0f && dot3(bc_n, ca_n) > 0.0f;
 }
 
@@ -446,7 +454,7 @@ __device__ __forceinline__ void walk_nodes(const MeshView &V, Walk &w, LaneStack
 }
 // the triangles of the leaf the lane holds (Triangle::intersect for each, the reference's test bit for bit), then the next
 // node off the stack
-template <bool PLAIN_STACK>
+template <bool PLAIN_STACK, bool EAGER = false>
 __device__ __forceinline__ void walk_leaf(const MeshView &V, Walk &w, LaneStack<PLAIN_STACK> &stack, Counters &cnt) {
 #if RRT_WALK_STATS == 2
     RRT_WS_WAVE_COUNT(2);
@@ -467,7 +475,7 @@ __device__ __forceinline__ void walk_leaf(const MeshView &V, Walk &w, LaneStack<
 #if RRT_WALK_STATS == 2
         RRT_WS_WAVE_COUNT(1);
 #endif
-        if (!tri_test(T, w.o, w.d, t, ent)) continue;
+        if (!tri_test<EAGER>(T, w.o, w.d, t, ent)) continue;
         if (t < 0.0f) continue;
         const uint32_t oi = V.orig[first + k];
         if (t < w.best || ((w.found || w.ties) && t == w.best && oi < w.best_orig)) {
@@ -485,7 +493,7 @@ __device__ __forceinline__ void walk_leaf(const MeshView &V, Walk &w, LaneStack<
 // PolyMesh::intersect (polymesh_object.rs:216-242): the closest hit of EITHER facing with t >= 0,
 // the lowest triangle index winning exact ties; only hits with t < tmax are reported (callers pass
 // the best distance so far: a farther mesh hit could not win anyway).  Returns the BVH slot.
-template <bool PLAIN_STACK, bool UNIFORM_MESH>
+template <bool PLAIN_STACK, bool UNIFORM_MESH, bool EAGER = false>
 __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &M, f3 o, f3 d, float tmax, Lds &lds, Counters &cnt,
                                              float &best_t, uint32_t &best_slot, bool &best_entering) {
     const MeshView V = mesh_view(S, M);
@@ -504,7 +512,7 @@ __device__ __forceinline__ bool mesh_closest(const DevScene &S, const MeshInfo &
     while (w.cur != RRT_WALK_DONE) {
         walk_nodes<PLAIN_STACK, UNIFORM_MESH>(V, w, stack, cnt);
         if (w.cur == RRT_WALK_DONE) break;
-        walk_leaf(V, w, stack, cnt);
+        walk_leaf<PLAIN_STACK, EAGER>(V, w, stack, cnt);
     }
 #if RRT_WALK_STATS == 1
     if (ws_on) {
@@ -747,7 +755,7 @@ struct CsgState {
 // 1 M-triangle frame).  Their cases are then not compiled at all: the compiler hoists the ray-dependent halves of their
 // arithmetic (squares and products of the direction, the cuboid's six dot products) in front of the record loop, where a
 // scene without such records paid them for every ray and every shadow ray (some 200 vector instructions per wave).
-enum SceneFeatures : int { FEAT_CSG = 1, FEAT_MESH = 2, FEAT_ALL = 3, FEAT_NO_SOLIDS = 4 };
+enum SceneFeatures : int { FEAT_CSG = 1, FEAT_MESH = 2, FEAT_ALL = 3, FEAT_NO_SOLIDS = 4, FEAT_TRI_EAGER = 8 };  // FEAT_TRI_EAGER: tri_test<true>
 
 // The one entering hit a single-primitive object can produce (list position 0 of a plane, t0 of a
 // sphere / quadric, the cuboid's first_hit, the mesh's closest hit when it faces the ray), with the
@@ -797,7 +805,7 @@ __device__ __forceinline__ bool single_entering_hit(const DevScene &S, const Pro
             float t;
             uint32_t slot;
             bool ent;
-            if (!mesh_closest<!(FEAT & FEAT_CSG), true>(S, S.meshes[r.aux], o, d, mesh_bound, lds, cnt, t, slot, ent)) return false;
+            if (!mesh_closest<!(FEAT & FEAT_CSG), true, (FEAT & FEAT_TRI_EAGER) != 0>(S, S.meshes[r.aux], o, d, mesh_bound, lds, cnt, t, slot, ent)) return false;
             if (!ent) return false;  // a nearer back face hides farther front faces
             t_out = t;
             sub_out = slot;
@@ -877,7 +885,7 @@ __device__ __forceinline__ bool object_step(const DevScene &S, uint32_t k, const
         const ProgRec &leaf = S.prog[k_out];
         float t;
         bool ent;
-        if (leaf.aux >= S.n_meshes || !mesh_closest<false, false>(S, S.meshes[leaf.aux], o, d, RRT_INF, lds, cnt, t, sub_out, ent)) return false;  // (the lane's own winner)
+        if (leaf.aux >= S.n_meshes || !mesh_closest<false, false, (FEAT & FEAT_TRI_EAGER) != 0>(S, S.meshes[leaf.aux], o, d, RRT_INF, lds, cnt, t, sub_out, ent)) return false;  // (the lane's own winner)
     }
     return true;
 }

@@ -525,6 +525,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == RRT_MODE_SCENE && (FEAT & FEAT_NO_S
     const uint32_t i = slot.i;
     const bool active = slot.active;
     if (slot.block_idle) return;  // launched for the predicted size of the level
+    // every instance but the fused single-level one of raytracing mode takes its triangle records in one round trip (tri_test)
+    constexpr int TF = FEAT | ((MODE == RRT_MODE_SCENE && FUSE) ? 0 : FEAT_TRI_EAGER);
     Counters cnt = {0, 0, 0, 0};
     GatherCounts gc;
     NodeOut N;
@@ -536,14 +538,14 @@ __global__ __launch_bounds__(BLOCK, (MODE == RRT_MODE_SCENE && (FEAT & FEAT_NO_S
         level_ray(A, i, o, d);
         TraceResult tr;
         RRT_WS_STAMP(ws_k1);
-        trace<FEAT>(S, o, d, lds, cnt, tr);
+        trace<TF>(S, o, d, lds, cnt, tr);
         RRT_WS_STAMP(ws_k2);
 #if RRT_WALK_STATS == 3
         RRT_WS_ADD(0, ws_k2 - ws_k1);
 #endif
         shade_node<MODE, FEAT, FUSE>(A, i, o, d, tr, cnt, gc, N, [&](uint32_t, f3 so, f3 sd, float limit) {
             RRT_WS_STAMP(ws_s0);
-            const bool occ = shadowtrace<FEAT>(S, so, sd, limit, lds, cnt);
+            const bool occ = shadowtrace<TF>(S, so, sd, limit, lds, cnt);
             RRT_WS_STAMP(ws_s1);
 #if RRT_WALK_STATS == 3
             RRT_WS_ADD(1, ws_s1 - ws_s0);
