@@ -157,13 +157,14 @@ struct LevelBuffers {
     float4 *ray_o;   // origin.xyz, w = parent index (level 0: pixel index) as uint bits
     float4 *ray_d;   // direction.xyz, w = child slot (0 reflection, 1 refraction) as uint bits
     float4 *once;    // fold of the non-Global parts' compute_once, w = kr
-    float4 *glob;    // wr, wt, n_parts-or-0 (compound divisor, 0 = not compound), flags
+    float4 *glob;    // wr, wt, depth (hit.distance; 0 for a miss), flags | compound divisor << NF_PARTS_SHIFT (n_parts, 0 = not compound)
     float4 *lights;  // [n_lights][capacity]: per-light term already multiplied by intensity; w = lit flag
-    float4 *result;  // colour.rgb, depth
+    float4 *result;  // levels >= 1, written by k_combine for the parents: colour.rgb, depth
     int2 *child;     // queue index of the reflection / refraction child at level+1, or -1
     uint32_t *object_id;
     uint32_t capacity;
 };
 enum NodeFlags : uint32_t { NF_HIT = 1, NF_HAS_GLOBAL = 2, NF_GLOBAL_ACTIVE = 4 /* depth < max_depth */ };
+#define NF_PARTS_SHIFT 8
 
 }  // namespace rrt

@@ -269,8 +269,7 @@ __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o,
         if (fuse) {
             write_pixel(A, out_pixel, mk3(0.0f, 0.0f, 0.0f), 0.0f, 0xFFFFFFFFu);
         } else {
-            node_store(&A.cur.result[i], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-            node_store(&A.cur.glob[i], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)));
+            node_store(&A.cur.glob[i], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)));  // (depth 0, no flags)
             A.cur.object_id[i] = 0xFFFFFFFFu;
         }
         return;
@@ -278,10 +277,7 @@ __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o,
     const DevMaterial &M = S.materials[h.material];
     uint32_t flags = NF_HIT;
     float kr = 0.0f;
-    if (!fuse) {
-        A.cur.object_id[i] = tr.object;
-        node_store(&A.cur.result[i], make_float4(0.0f, 0.0f, 0.0f, tr.t));  // depth = hit.distance (scene.rs:124-127)
-    }
+    if (!fuse) A.cur.object_id[i] = tr.object;
     if (MODE == RRT_MODE_SCENE) {
         f3 once = material_once_pre(S, M, h, cnt);
         const float div = M.is_compound ? (float)M.n_parts : 0.0f;
@@ -329,7 +325,8 @@ __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o,
                 }
             }
             node_store(&A.cur.once[i], make_float4(once.x, once.y, once.z, kr));
-            node_store(&A.cur.glob[i], make_float4(wr, wt, div, __uint_as_float(flags)));
+            // depth = hit.distance (scene.rs:124-127); the compound divisor rides in the flag word (NF_PARTS_SHIFT)
+            node_store(&A.cur.glob[i], make_float4(wr, wt, tr.t, __uint_as_float(flags | (M.is_compound ? (uint32_t)M.n_parts << NF_PARTS_SHIFT : 0u))));
         }
     } else {  // PhotonScene::vueontrace, photon_scene.rs:309-361
         float sw = M.surface_weight, rw = M.w[3];
@@ -367,7 +364,7 @@ __device__ __forceinline__ void shade_node(const TraceArgs &A, uint32_t i, f3 o,
             }
         }
         node_store(&A.cur.once[i], make_float4(surface.x, surface.y, surface.z, 0.0f));
-        node_store(&A.cur.glob[i], make_float4(rw, sw, 0.0f, __uint_as_float(flags)));
+        node_store(&A.cur.glob[i], make_float4(rw, sw, tr.t, __uint_as_float(flags)));
     }
 }
 
@@ -644,7 +641,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
     if (!slot.active) return;
     float4 g = node_load(&A.cur.glob[i]);
     uint32_t flags = __float_as_uint(g.w);
-    float4 res = node_load(&A.cur.result[i]);
+    const float depth = g.z;
     f3 colour = mk3(0.0f, 0.0f, 0.0f);
     if (flags & NF_HIT) {
         float4 on = node_load(&A.cur.once[i]);
@@ -660,7 +657,7 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
             cb = mk3(r.x, r.y, r.z);
         }
         if (A.mode == RRT_MODE_SCENE) {
-            float wr = g.x, wt = g.y, div = g.z, kr = on.w;
+            float wr = g.x, wt = g.y, div = (float)(flags >> NF_PARTS_SHIFT), kr = on.w;
             f3 total = scene_node_total(once, flags, wr, wt, div, kr, ch.x >= 0, ca, ch.y >= 0, cb);
             colour = total;
             for (uint32_t l = 0; l < A.S.n_lights; l++) {  // scene.rs:116-121
@@ -676,11 +673,12 @@ __global__ __launch_bounds__(RRT_BLOCK) void k_combine(TraceArgs A) {
             colour = colour / (sw + rw + rw);
         }
     }
-    A.cur.result[i] = make_float4(colour.x, colour.y, colour.z, res.w);
-    if (A.level == 0) {
+    if (A.level == 0) {  // (nobody reads level 0's result: the colour goes to the frame)
         uint32_t px, py;
         uint32_t pixel = A.cam.width ? frame_pixel(A, A.pixel_base + i, px, py) : A.pixel_base + i;
-        write_pixel(A, pixel, colour, res.w, A.cur.object_id[i]);
+        write_pixel(A, pixel, colour, depth, A.cur.object_id[i]);
+    } else {
+        A.cur.result[i] = make_float4(colour.x, colour.y, colour.z, depth);
     }
 }
 
