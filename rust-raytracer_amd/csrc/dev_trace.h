@@ -907,6 +907,38 @@ __device__ __forceinline__ bool object_step(const DevScene &S, uint32_t k, const
 #else
 #define RRT_KEEP_IN_LOOP(o, d)
 #endif
+// Record k of the wave-uniform program, taken as a whole with ONE scalar load.  Left to itself the compiler loads the op
+// word, waits, branches on it and only then asks for the parameters (two or three dependent round trips per record; a lone
+// wave of a deep recursion level spends most of its time in them).  The record then lives in 16 scalar registers instead of
+// being picked apart through vector ones: the raytraced CSG kernel drops from 141 registers + scratch to 122 (four waves per
+// SIMD), C2 10.06 -> 10.37 Grays/s one frame at a time, 15.5 -> 17.2 with three in flight; mirror / glass teapots + 1-2 %.
+// WHOLE = false: the fused instance for planes and meshes (two or three records per ray, and 48 more scalar spills at its
+// 128-register bound: 0.747 -> 0.755 ms on the 4K mesh frame) keeps the compiler's loads.
+template <bool WHOLE>
+struct RecordLoad {  // WHOLE = false: the record where it lies
+    static __device__ __forceinline__ const ProgRec &get(const ProgRec *prog, uint32_t k) { return prog[k]; }
+};
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RRT_NO_REC_X16)
+template <>
+struct RecordLoad<true> {
+    static __device__ __forceinline__ ProgRec get(const ProgRec *prog, uint32_t k) {
+        typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+        const uint64_t base = (uint64_t)reinterpret_cast<uintptr_t>(prog + k);
+        const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base), b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+        const uint64_t addr = ((uint64_t)b_hi << 32) | (uint64_t)b_lo;
+        u32x16 v;
+        // (no "memory" clobber, not volatile: the program is read-only while the kernel runs)
+        asm("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(addr));
+        ProgRec r;
+        r.op = v[0], r.object = v[1], r.material = (int32_t)v[2], r.aux = v[3];
+#pragma unroll
+        for (int j = 0; j < 12; j++) r.p[j] = __uint_as_float(v[4 + j]);
+        return r;
+    }
+};
+#endif
+template <int FEAT>
+constexpr bool whole_records() { return !((FEAT & FEAT_NO_SOLIDS) && !(FEAT & FEAT_TRI_EAGER)); }
 template <int FEAT = FEAT_ALL>
 __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, Counters &cnt, TraceResult &r) {
     r.object = 0xFFFFFFFFu;
@@ -918,7 +950,7 @@ __device__ __forceinline__ void trace(const DevScene &S, f3 o, f3 d, Lds &lds, C
     if (S.has_bounds) rb = make_raybox(o, d);
     for (uint32_t k = 0; k < S.n_prog; k++) {
         RRT_KEEP_IN_LOOP(o, d);
-        const ProgRec &rec = S.prog[k];
+        const ProgRec &rec = RecordLoad<whole_records<FEAT>()>::get(S.prog, k);  // (a temporary lives as long as the reference)
         if ((rec.op & 0xFFu) == OP_BOUND) {
             if ((FEAT & FEAT_CSG) && (rec.op & PF_FIRST)) csg.reset();
             if (!__any(bound_hit(rec, rb, o))) {
@@ -948,7 +980,7 @@ __device__ __forceinline__ bool shadowtrace(const DevScene &S, f3 o, f3 d, float
     if (S.has_bounds) rb = make_raybox(o, d);
     for (uint32_t k = 0; k < S.n_prog; k++) {
         RRT_KEEP_IN_LOOP(o, d);
-        const ProgRec &rec = S.prog[k];
+        const ProgRec &rec = RecordLoad<whole_records<FEAT>()>::get(S.prog, k);  // (a temporary lives as long as the reference)
         if ((rec.op & 0xFFu) == OP_BOUND) {
             if ((FEAT & FEAT_CSG) && (rec.op & PF_FIRST)) csg.reset();
             if (!__any(bound_hit(rec, rb, o))) {
