@@ -890,7 +890,7 @@ __global__ void k_tri_records(const float *pos, const uint32_t *order, uint32_t 
     t.a_nx = make_float4(a.x, a.y, a.z, nrm.x);
     t.b_ny = make_float4(b.x, b.y, b.z, nrm.y);
     t.c_nz = make_float4(c.x, c.y, c.z, nrm.z);
-    t.d_pad = make_float4(d, 0.0f, 0.0f, 0.0f);
+    t.d_pad = make_float4(d, __uint_as_float(src), 0.0f, 0.0f);
     tris[k] = t;
     tri_index[k] = src;
 }

@@ -59,7 +59,7 @@ struct TriHot {
     float4 a_nx;  // a.xyz, plane normal x
     float4 b_ny;  // b.xyz, plane normal y
     float4 c_nz;  // c.xyz, plane normal z
-    float4 d_pad; // plane d, 0, 0, 0
+    float4 d_pad; // plane d, the triangle's index in its mesh as uint bits (= tri_index: ties go to the lowest, and the walk has it with the record), 0, 0
 };
 struct MeshInfo {
     uint32_t tri_first, tri_count;

@@ -236,6 +236,11 @@ __device__ __forceinline__ void cuboid_hits(const ProgRec &C, f3 o, f3 d, bool &
 // Triangle::intersect (triangle_object.rs:129-160) on the finite plane hit only (the infinite ones
 // can never be selected: see DESIGN.md "mesh semantics").  Returns true when the hit point passes
 // the same-side test; `entering` is the plane hit's facing.
+__device__ __forceinline__ uint32_t tri_index_of(const TriHot &T) {
+    uint32_t u;
+    memcpy(&u, &T.d_pad.y, sizeof(u));
+    return u;
+}
 template <bool EAGER = false>
 __device__ __forceinline__ bool tri_test(const TriHot &T, f3 o, f3 d, float &t, bool &entering) {
     f3 n = mk3(T.a_nx.w, T.b_ny.w, T.c_nz.w);
@@ -477,7 +482,7 @@ __device__ __forceinline__ void walk_leaf(const MeshView &V, Walk &w, LaneStack<
 #endif
         if (!tri_test<EAGER>(T, w.o, w.d, t, ent)) continue;
         if (t < 0.0f) continue;
-        const uint32_t oi = V.orig[first + k];
+        const uint32_t oi = tri_index_of(T);  // (= V.orig[first + k], without another load behind the test)
         if (t < w.best || ((w.found || w.ties) && t == w.best && oi < w.best_orig)) {
             w.found = true;
             w.best = t;

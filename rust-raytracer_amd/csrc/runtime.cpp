@@ -346,7 +346,9 @@ void emit(Flat &F, const HostObject &o, const Box &enclosing) {
                         t.a_nx = make_float4(a.x, a.y, a.z, nrm.x);
                         t.b_ny = make_float4(b.x, b.y, b.z, nrm.y);
                         t.c_nz = make_float4(c.x, c.y, c.z, nrm.z);
-                        t.d_pad = make_float4(d, 0.0f, 0.0f, 0.0f);
+                        float index_bits;
+                        memcpy(&index_bits, &order[k], sizeof(index_bits));
+                        t.d_pad = make_float4(d, index_bits, 0.0f, 0.0f);
                         F.tris[tri_base + k] = t;
                         F.tri_index[tri_base + k] = order[k];
                     }
