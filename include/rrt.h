@@ -68,8 +68,10 @@ typedef struct rrt_params {
     uint32_t gather_heavy_threshold;    /* photon mode: a radiance estimate whose two query boxes hold more candidate
                                            records than this is gathered by a whole wave in a second kernel instead of by
                                            its lane.  0 = default: derived from the photon maps at rrt_photon_build (4 x the
-                                           candidate records of a typical query, at least 2048); 0xFFFFFFFF = never.  Same
-                                           photons; the f32 sums are added in another (fixed) order                     */
+                                           candidate records of a typical query, at least 2048; vueons behind the first
+                                           level, few and incoherent, hand over at an eighth of that, not below 256);
+                                           a value given here holds for every level; 0xFFFFFFFF = never.  Same photons;
+                                           the f32 sums are added in another (fixed) order                              */
     uint32_t gather_k;                  /* photon mode: 0 (default) = the reference's estimator, every photon inside the cube
                                            (photon_scene.rs:393 get_within_distance); k > 0 = PhotonTree::get_n_within_radius
                                            (photon_tree.rs:41-50, written but never called by the reference) as the estimator:
