@@ -917,6 +917,8 @@ __device__ __forceinline__ bool object_step(const DevScene &S, uint32_t k, const
 // wave of a deep recursion level spends most of its time in them).  The record then lives in 16 scalar registers instead of
 // being picked apart through vector ones: the raytraced CSG kernel drops from 141 registers + scratch to 122 (four waves per
 // SIMD), C2 10.06 -> 10.37 Grays/s one frame at a time, 15.5 -> 17.2 with three in flight; mirror / glass teapots + 1-2 %.
+// The load is scalar: k must be the same in every active lane -- it is in the record loops of trace / shadowtrace, whose
+// only jumps (`k += rec.aux` behind a bound that every lane misses) are decided by __any.
 // WHOLE = false: the fused instance for planes and meshes (two or three records per ray, and 48 more scalar spills at its
 // 128-register bound: 0.747 -> 0.755 ms on the 4K mesh frame) keeps the compiler's loads.
 template <bool WHOLE>
