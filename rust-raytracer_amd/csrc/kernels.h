@@ -104,6 +104,9 @@ struct TraceArgs {
     uint32_t count;       // level 0: rays in this level.  Striped levels: rays per stripe this launch covers
     const uint32_t *count_ptr;  // striped levels: the level's stripe counters (the previous level's appends wrote them); level 0: null
     uint32_t striped;     // 0: level 0 (nodes [0, count)); 1: a striped level
+    uint32_t lane_shift;  // striped trace launches: a block works on 64 >> lane_shift rays (2: sixteen lanes of every wave busy).
+                          // Small levels of incoherent rays last as long as their slowest wave, and a wave as long as the longest
+                          // of its lanes' walks, phase by phase: fewer rays per wave, shorter waves (set_level_args)
     uint32_t stripe_cap;  // striped levels: nodes per stripe the level's arrays hold
     uint32_t next_stripe_cap;  // nodes per stripe of the next level: appends beyond it raise RRT_ERR_BIT_QUEUE (0: nothing may be appended)
     uint32_t level;       // recursion depth of these rays

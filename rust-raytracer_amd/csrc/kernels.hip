@@ -387,10 +387,11 @@ __device__ __forceinline__ NodeSlot node_slot(const TraceArgs &A) {
         // next stripe: every stripe is worked on by all XCDs.  (Stripe s on XCD s % 8 alone was measured: a level whose costly
         // rays come from one patch of the frame then runs on an eighth of the GPU -- level 1 of the photon-mapped scene2
         // frame, 114 k rays, 0.56 -> 0.67 ms.)
-        const uint32_t s = (blockIdx.x >> 3) % RRT_STRIPES, first = ((blockIdx.x & 7u) + ((blockIdx.x / (8u * RRT_STRIPES)) << 3)) * BLOCK;
+        const uint32_t per_block = BLOCK >> A.lane_shift;  // rays of the block (k_combine: lane_shift 0)
+        const uint32_t s = (blockIdx.x >> 3) % RRT_STRIPES, first = ((blockIdx.x & 7u) + ((blockIdx.x / (8u * RRT_STRIPES)) << 3)) * per_block;
         const uint32_t have = min(A.count_ptr[s * RRT_STRIPE_STRIDE], A.stripe_cap);
         n.i = s * A.stripe_cap + first + threadIdx.x;
-        n.active = first + threadIdx.x < have;
+        n.active = threadIdx.x < per_block && first + threadIdx.x < have;
         n.block_idle = first >= have;
     }
     return n;
@@ -815,6 +816,7 @@ static inline uint32_t stripe_blocks(uint32_t blocks, uint32_t striped) { return
 
 void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream) {
     if (a.count == 0) return;
+    const uint32_t per_block = a.striped ? 64u >> a.lane_shift : 64u;  // rays per block (node_slot)
     // one instance per (mode, scene feature set): see SceneFeatures in dev_trace.h
     int feat = (a.S.has_csg ? FEAT_CSG : 0) | (a.S.n_meshes ? FEAT_MESH : 0);
     if (feat == FEAT_MESH && a.S.no_solids) feat |= FEAT_NO_SOLIDS;  // planes and meshes only
@@ -827,7 +829,7 @@ void launch_trace_shade(const TraceArgs &a, size_t lds_bytes, hipStream_t stream
     // striped over RRT_STRIPES counters it gains as well (kernels 0.450 -> 0.437 ms per frame) and the 256-thread
     // instances are gone.
 #define RRT_NARROW(M, F, U) \
-    hipLaunchKernelGGL((k_trace_shade<M, F, 64, U>), dim3(stripe_blocks((a.count + 63u) / 64u, a.striped)), dim3(64), lds_bytes / 256 * 64, stream, a)
+    hipLaunchKernelGGL((k_trace_shade<M, F, 64, U>), dim3(stripe_blocks((a.count + per_block - 1u) / per_block, a.striped)), dim3(64), lds_bytes / 256 * 64, stream, a)
 #define RRT_EITHER(WHICH, M, F)    \
     do {                           \
         if (a.fuse)                \
@@ -875,8 +877,10 @@ void launch_gather_heavy(const TraceArgs &a, hipStream_t stream) {
         hipLaunchKernelGGL(k_gather_heavy<false>, dim3(4096), dim3(64), 0, stream, a);
 }
 
-void launch_combine(const TraceArgs &a, hipStream_t stream) {
-    if (a.count == 0) return;
+void launch_combine(const TraceArgs &a0, hipStream_t stream) {
+    if (a0.count == 0) return;
+    TraceArgs a = a0;
+    a.lane_shift = 0;  // (full blocks: the pass is bound by its bytes)
     hipLaunchKernelGGL(k_combine, dim3(stripe_blocks(blocks_for(a.count), a.striped)), dim3(RRT_BLOCK), 0, stream, a);
 }
 void launch_batch_trace(const BatchTraceArgs &a, size_t lds_bytes, hipStream_t stream) {
